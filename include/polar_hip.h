@@ -1,0 +1,104 @@
+/*
+ * polar_hip.h -- C ABI of libpolar_hip.so, the MI355X (gfx950) polar-code path.
+ *
+ * Drop-in boundary for the hot path of xdsopl/polar: every entry point below replaces one
+ * functor call of the reference (cited per function, paths relative to the reference
+ * checkout). Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ *
+ * Buffer layout is the reference's SIMD layout with W = frames: element-major / frame-minor,
+ * buf[frames * i + k] = element i of frame k (testbench.cc:134-139, 143-146, 179-182).
+ * Symbols: +1 = bit 0, -1 = bit 1, 0 = erasure; LLR sign convention log p(+1)/p(-1)
+ * (testbench.cc:160). `frozen` holds one byte (0/1) per code position; `program` is the
+ * byte-code of PolarCompiler (polar_compiler.hh:11-13, 51-58).
+ *
+ * The reference has no error channel (asserts only, Makefile:2); here every call returns
+ * POLAR_OK (0) or a negative POLAR_E_* code, and inputs on which the reference would trip
+ * an assert are rejected with POLAR_E_PROGRAM / POLAR_E_ARG instead of aborting.
+ *
+ * Threading: a handle owns device scratch, like the reference functor objects own theirs
+ * (polar_decoder.hh:128-129); one call at a time per handle, any number of handles.
+ */
+#ifndef POLAR_HIP_H
+#define POLAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct polar_hip_handle polar_hip_handle;
+
+enum {
+	POLAR_OK = 0,
+	POLAR_E_ARG = -1,     /* bad argument (null pointer, level out of range, unknown id) */
+	POLAR_E_PROGRAM = -2, /* malformed program / frozen set: the reference would assert */
+	POLAR_E_HIP = -3,     /* a HIP runtime call failed, see polar_hip_last_error() */
+	POLAR_E_NOMEM = -4,   /* device or host allocation failed */
+	POLAR_E_NODEVICE = -5 /* no usable gfx950 device */
+};
+
+/* where the data pointers of a call live */
+enum { POLAR_HOST = 0, POLAR_DEVICE = 1 };
+
+/* Human-readable text for the last failure on this thread. */
+const char *polar_hip_last_error(void);
+
+/* ---- host-side code construction (stays on the CPU, as in the reference) ---- */
+
+/* PolarCodeConst0<MAX_M>::operator() polar_freezer.hh:49-61. Returns POLAR_OK. */
+int polar_code_const0(uint8_t *frozen, int level, int K, long double erasure_probability);
+/* PolarFreezer::operator() polar_freezer.hh:23-31. Returns K (>= 0). */
+int polar_freezer(uint8_t *frozen, int level, long double erasure_probability, long double freezing_threshold);
+/* PolarCompiler::operator() polar_compiler.hh:51-58. `program` needs room for 2N+1 bytes in
+ * the worst case (N suffices for polar-ordered frozen sets, testbench.cc:95-97). Returns the
+ * program length in bytes, or POLAR_E_PROGRAM where the reference asserts (polar_compiler.hh:23). */
+int polar_compile(uint8_t *program, const uint8_t *frozen, int level);
+/* Number of message symbols per frame a program emits (K), or POLAR_E_PROGRAM. */
+int polar_program_rows(const uint8_t *program, int length);
+
+/* ---- device objects ---- */
+
+/* Creates a decoder/encoder context on HIP device `device` (replaces constructing the
+ * reference functor objects, testbench.cc:83, 94, 100). */
+int polar_hip_create(polar_hip_handle **out, int device);
+void polar_hip_destroy(polar_hip_handle *h);
+
+/* Tuning: frames per wavefront (4, 8, 16, 32 or 64), highest LLR level staged in LDS, and
+ * the number of resident wavefronts (0 = fill the device). Defaults are chosen per code size. */
+int polar_hip_configure(polar_hip_handle *h, int frames_per_wave, int lds_level, int max_waves);
+
+/* Uploads a PolarCompiler program as the constant-memory instruction stream; returns a
+ * program id >= 0. (polar_decoder.hh:131 takes the program per call; here it is resident.) */
+int polar_hip_load_program(polar_hip_handle *h, const uint8_t *program, int length);
+
+/* PolarDecoder<TYPE,MAX_M>::operator()(message, codeword, program) polar_decoder.hh:131-464
+ * for `frames` frames at once. codeword: N x frames int8 LLRs (not modified);
+ * message: K x frames int8 decisions. `where` says whether both pointers are host or device. */
+int polar_hip_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, int where);
+/* Same, enqueued on `stream` (a hipStream_t) without synchronising; device pointers only. */
+int polar_hip_decode_async(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, void *stream);
+
+/* PolarEncoder<TYPE,M>::operator() polar_encoder.hh:15-27 (systematic = 0) and
+ * PolarSysEnc<TYPE,M>::operator() polar_encoder.hh:36-58 (systematic = 1).
+ * message: K x frames, codeword: N x frames. */
+int polar_hip_encode(polar_hip_handle *h, int systematic, int8_t *codeword, const int8_t *message, const uint8_t *frozen, int level, size_t frames, int where);
+
+/* Post-decode step of the systematic bench, testbench.cc:177-183: re-encode the decoded u
+ * with the non-systematic encoder and gather the information positions, in place on
+ * `decoded` (K x frames). */
+int polar_hip_systematic_extract(polar_hip_handle *h, int8_t *decoded, const uint8_t *frozen, int level, size_t frames, int where);
+
+/* Blocks until all work enqueued through this handle has finished. */
+int polar_hip_synchronize(polar_hip_handle *h);
+
+/* Milliseconds the GPU spent in the decode kernel of the last polar_hip_decode call
+ * (HIP events on the launch stream), or a negative error. */
+float polar_hip_last_decode_ms(polar_hip_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,204 @@
+"""Host-side mirror of the reference's functor interface over the C ABI (include/polar_hip.h).
+
+Same names and argument meaning as the reference classes; buffers are numpy arrays (host) or
+torch CUDA tensors / raw device pointers (device) in the reference's element-major /
+frame-minor layout, shape [elements][frames] (testbench.cc:134-139). Where the reference
+asserts, these raise PolarError.
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import lib
+
+HOST, DEVICE = 0, 1
+
+
+class PolarError(RuntimeError):
+    def __init__(self, code, where):
+        msg = lib.polar_hip_last_error()
+        super().__init__("%s failed (%d): %s" % (where, code, msg.decode() if msg else ""))
+        self.code = code
+
+
+def _check(rc, where):
+    if rc < 0:
+        raise PolarError(rc, where)
+    return rc
+
+
+def _ptr(a):
+    """(pointer, where) of a numpy array, a torch tensor or None."""
+    if a is None:
+        return None, None
+    if isinstance(a, np.ndarray):
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("buffers must be C-contiguous [elements][frames]")
+        return ctypes.c_void_p(a.ctypes.data), HOST
+    if hasattr(a, "data_ptr"):  # torch tensor
+        if not a.is_contiguous():
+            raise ValueError("buffers must be contiguous [elements][frames]")
+        return ctypes.c_void_p(a.data_ptr()), DEVICE if a.is_cuda else HOST
+    raise TypeError("expected a numpy array or a torch tensor")
+
+
+def _where(*ws):
+    ws = [w for w in ws if w is not None]
+    if any(w != ws[0] for w in ws):
+        raise ValueError("all buffers of one call must live on the same side (host or device)")
+    return ws[0] if ws else HOST
+
+
+def testbench_probability():
+    """Erasure probability the reference bench feeds PolarCodeConst0 for rate 1/2 (testbench.cc:74-87)."""
+    import math
+
+    design = 10.0 * math.log10(-math.log(0.5))
+    return math.exp(-(10.0 ** ((design + 1.59175) / 10.0)))
+
+
+class PolarCodeConst0:
+    """polar_freezer.hh:34-62. __call__(frozen, level, K, erasure_probability=exp(-1))."""
+
+    def __call__(self, frozen_bits, level, K, erasure_probability=0.36787944117144233):
+        assert frozen_bits.dtype == np.uint8 and frozen_bits.size >= (1 << level)
+        _check(lib.polar_code_const0(frozen_bits.ctypes.data, level, K, erasure_probability), "PolarCodeConst0")
+
+
+class PolarFreezer:
+    """polar_freezer.hh:11-32. __call__(frozen, level, erasure_probability=0.5, threshold=0.5) -> K."""
+
+    def __call__(self, frozen_bits, level, erasure_probability=0.5, freezing_threshold=0.5):
+        assert frozen_bits.dtype == np.uint8 and frozen_bits.size >= (1 << level)
+        return _check(lib.polar_freezer(frozen_bits.ctypes.data, level, erasure_probability, freezing_threshold), "PolarFreezer")
+
+
+class PolarCompiler:
+    """polar_compiler.hh:9-59. __call__(program, frozen, level) -> length in bytes."""
+
+    def __call__(self, program, frozen, level):
+        assert program.dtype == np.uint8 and frozen.dtype == np.uint8
+        if program.size < 2 * (1 << level) + 1:
+            # the reference trusts the caller (testbench.cc:95 gives N bytes); refuse what could overflow
+            probe = np.zeros(2 * (1 << level) + 1, np.uint8)
+            n = _check(lib.polar_compile(probe.ctypes.data, frozen.ctypes.data, level), "PolarCompiler")
+            if n > program.size:
+                raise ValueError("program buffer too small: need %d bytes" % n)
+            program[:n] = probe[:n]
+            return n
+        return _check(lib.polar_compile(program.ctypes.data, frozen.ctypes.data, level), "PolarCompiler")
+
+
+class Session:
+    """Owns one device context (decoder scratch, resident programs), like the reference's
+    heap-allocated functor objects (testbench.cc:83,100)."""
+
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        _check(lib.polar_hip_create(ctypes.byref(h), device), "polar_hip_create")
+        self._h = h
+        self._programs = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.polar_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def configure(self, frames_per_wave=0, lds_level=0, max_waves=0):
+        _check(lib.polar_hip_configure(self._h, frames_per_wave, lds_level, max_waves), "polar_hip_configure")
+
+    def load_program(self, program):
+        program = np.ascontiguousarray(program, np.uint8)
+        key = program.tobytes()
+        if key not in self._programs:
+            pid = _check(lib.polar_hip_load_program(self._h, program.ctypes.data, program.size), "polar_hip_load_program")
+            rows = _check(lib.polar_program_rows(program.ctypes.data, program.size), "polar_program_rows")
+            self._programs[key] = (pid, rows)
+        return self._programs[key]
+
+    def synchronize(self):
+        _check(lib.polar_hip_synchronize(self._h), "polar_hip_synchronize")
+
+    def last_decode_ms(self):
+        ms = lib.polar_hip_last_decode_ms(self._h)
+        if ms < 0:
+            raise PolarError(int(ms), "polar_hip_last_decode_ms")
+        return ms
+
+
+_default_session = None
+
+
+def _session(session):
+    global _default_session
+    if session is not None:
+        return session
+    if _default_session is None:
+        _default_session = Session(0)
+    return _default_session
+
+
+def _frames(a):
+    return int(a.shape[1]) if a.ndim == 2 else 1
+
+
+class PolarDecoder:
+    """polar_decoder.hh:9-465: __call__(message, codeword, program)."""
+
+    def __init__(self, session=None):
+        self.session = _session(session)
+
+    def __call__(self, message, codeword, program):
+        pid, rows = self.session.load_program(program)
+        frames = _frames(codeword)
+        n = 1 << int(np.asarray(program).ravel()[0])
+        if codeword.shape[0] != n or (rows and (message.shape[0] < rows or _frames(message) != frames)):
+            raise ValueError("buffer shapes do not match the program: codeword [%d][F], message [>=%d][F]" % (n, rows))
+        mp, mw = _ptr(message)
+        cp, cw = _ptr(codeword)
+        _check(lib.polar_hip_decode(self.session._h, pid, mp, cp, frames, _where(mw, cw)), "PolarDecoder")
+
+    def launch(self, message, codeword, program, stream):
+        """Enqueue on a HIP stream without synchronising (device buffers only)."""
+        pid, _ = self.session.load_program(program)
+        mp, _w = _ptr(message)
+        cp, _w = _ptr(codeword)
+        _check(lib.polar_hip_decode_async(self.session._h, pid, mp, cp, _frames(codeword), ctypes.c_void_p(stream)), "PolarDecoder.launch")
+
+
+class _Encoder:
+    systematic = 0
+
+    def __init__(self, M, session=None):
+        self.M = M
+        self.session = _session(session)
+
+    def __call__(self, codeword, message, frozen):
+        frozen = np.ascontiguousarray(frozen, np.uint8)
+        if codeword.shape[0] != (1 << self.M) or frozen.size != (1 << self.M):
+            raise ValueError("codeword / frozen must have N = %d rows" % (1 << self.M))
+        cp, cw = _ptr(codeword)
+        mp, mw = _ptr(message)
+        _check(lib.polar_hip_encode(self.session._h, self.systematic, cp, mp, frozen.ctypes.data, self.M, _frames(codeword), _where(cw, mw)), type(self).__name__)
+
+
+class PolarEncoder(_Encoder):
+    """polar_encoder.hh:9-28: __call__(codeword, message, frozen)."""
+
+    def extract_systematic(self, decoded, frozen):
+        """testbench.cc:177-183: re-encode `decoded` and gather the information positions, in place."""
+        frozen = np.ascontiguousarray(frozen, np.uint8)
+        dp, dw = _ptr(decoded)
+        _check(lib.polar_hip_systematic_extract(self.session._h, dp, frozen.ctypes.data, self.M, _frames(decoded), dw), "extract_systematic")
+
+
+class PolarSysEnc(_Encoder):
+    """polar_encoder.hh:30-59: __call__(codeword, message, frozen)."""
+
+    systematic = 1

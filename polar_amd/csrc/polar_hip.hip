@@ -1,0 +1,639 @@
+// polar_hip.hip -- kernels and C ABI of libpolar_hip.so (gfx950 only).
+//
+//   sc_decode_kernel   : batched SC decoder, one wavefront per group of 4*Q frames
+//                        (sc_core.hpp; replaces PolarDecoder::operator(), polar_decoder.hh:131)
+//   butterfly_kernel   : polar transform stages for the encoders (polar_encoder.hh:15-58)
+//   gather_rows_kernel : systematic extraction (testbench.cc:179-182)
+//
+// Everything here fails loudly: there is no CPU fallback for any device entry point.
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/polar_hip.h"
+#include "construct.hpp"
+#include "program.hpp"
+#include "sc_core.hpp"
+
+using namespace polar;
+
+static thread_local std::string g_error;
+
+static int fail(int code, const std::string &msg)
+{
+	g_error = msg;
+	return code;
+}
+
+#define HIP_TRY(expr) \
+	do { \
+		hipError_t e_ = (expr); \
+		if (e_ != hipSuccess) \
+			return fail(e_ == hipErrorOutOfMemory ? POLAR_E_NOMEM : POLAR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+	} while (0)
+
+// ---------------------------------------------------------------------------------------
+// decoder kernel
+// ---------------------------------------------------------------------------------------
+
+struct DecodeArgs {
+	const DevOp *prog;
+	const uint8_t *cw;
+	uint8_t *msg;
+	u32 *scratch;          // per-block arenas, block_dwords each
+	size_t block_dwords;
+	size_t frames;
+	u32 groups;
+	int top;
+	int aligned;           // cw and msg are 4-byte aligned
+};
+
+// Persistent wavefronts: block b walks the groups b, b + gridDim, ... Blocks are dealt to
+// the 8 XCDs round-robin, so within one sweep the blocks that share an XCD (equal b % 8) take
+// neighbouring groups: those groups share the 128-byte lines of every input row.
+template <int Q, int RL>
+__global__ void __launch_bounds__(64) sc_decode_kernel(DecodeArgs a)
+{
+	typedef Group<Q, RL> G;
+	__shared__ __attribute__((aligned(16))) u32 lds[G::LDS_DWORDS];
+	const u32 nb = gridDim.x, b = blockIdx.x;
+	const u32 slot = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+	u32 *arena = a.scratch ? a.scratch + (size_t)b * a.block_dwords : nullptr;
+	const size_t plane = ((size_t)Q << a.top) / 8;
+	G g;
+	g.sl = lds;
+	g.hls = lds + G::LDS_SOFT;
+	g.hlz = g.hls + G::LDS_PLANE;
+	g.tl = g.hlz + G::LDS_PLANE;
+	g.sg = arena;
+	g.hgs = arena ? arena + ((size_t)Q << a.top) : nullptr;
+	g.hgz = arena ? g.hgs + plane : nullptr;
+	g.top = a.top;
+	for (u32 base = 0; base < a.groups; base += nb) {
+		u32 grp = base + slot;
+		if (grp >= a.groups)
+			continue;
+		size_t g0 = (size_t)grp * (4 * Q);
+		size_t left = a.frames - g0;
+		int valid = left < (size_t)(4 * Q) ? (int)left : 4 * Q;
+		bool fast = a.aligned && valid == 4 * Q && a.frames % 4 == 0;
+		g.in = InVec<Q>{a.cw + g0, a.frames, valid, fast};
+		g.out = OutRows<Q>{a.msg + g0, a.frames, valid, fast};
+		g.run(a.prog);
+	}
+}
+
+typedef void (*decode_kernel_t)(DecodeArgs);
+
+struct KernelVariant {
+	int q, rl;
+	decode_kernel_t fn;
+	size_t lds_bytes;
+};
+
+#define VARIANT(q, rl) {q, rl, sc_decode_kernel<q, rl>, sizeof(u32) * (size_t)Group<q, rl>::LDS_DWORDS}
+static const KernelVariant g_variants[] = {
+	// ~20 KB of LDS per wavefront (7-8 wavefronts per CU)
+	VARIANT(1, 11), VARIANT(2, 10), VARIANT(4, 9), VARIANT(8, 8), VARIANT(16, 7),
+	// ~40 KB (3-4 per CU)
+	VARIANT(1, 12), VARIANT(2, 11), VARIANT(4, 10), VARIANT(8, 9), VARIANT(16, 8),
+	// ~10 KB (15-16 per CU)
+	VARIANT(2, 9), VARIANT(4, 8), VARIANT(8, 7), VARIANT(16, 6),
+};
+#undef VARIANT
+
+// ---------------------------------------------------------------------------------------
+// encoder kernels
+// ---------------------------------------------------------------------------------------
+
+// Symbols in {-1,0,+1} as two masks per byte: neg = bit 7, nz = bit 0. The reference multiplies
+// symbols (qmul, polar_helper.hh:145-152): the product negates by xor and is nonzero by and.
+template <typename T> struct Word;
+template <> struct Word<u32> { static const u32 NEG = 0x80808080u, NZ = 0x01010101u; };
+template <> struct Word<uint8_t> { static const u32 NEG = 0x80u, NZ = 0x01u; };
+
+enum { LOAD_INPLACE = 0, LOAD_MESSAGE = 1, LOAD_REFREEZE = 2 };
+
+// Stages h = 2^s0 .. 2^(s0+C-1) of the transform (polar_encoder.hh:17-26), 2^C rows per thread
+// in registers. cols = row length in units of T. src_row[i] = message row feeding code
+// position i, or -1 where the position is frozen (+1), used by LOAD_MESSAGE / LOAD_REFREEZE.
+template <typename T, int C>
+__global__ void __launch_bounds__(256) butterfly_kernel(T *cw, const T *msg, const int *src_row, size_t cols, int level, int s0, int mode)
+{
+	const size_t colblocks = (cols + 255) / 256;
+	const size_t col = (blockIdx.x % colblocks) * 256 + threadIdx.x;
+	if (col >= cols)
+		return;
+	const int c = level - s0 < C ? level - s0 : C; // stages in this pass
+	const size_t j = blockIdx.x / colblocks;       // enumerates rows with bits [s0, s0+c) clear
+	const size_t low = j & (((size_t)1 << s0) - 1);
+	const size_t row0 = ((j >> s0) << (s0 + c)) | low;
+	u32 neg[1 << C], nz[1 << C];
+#pragma unroll
+	for (int k = 0; k < (1 << C); ++k) {
+		if (k < (1 << c)) {
+			size_t row = row0 + ((size_t)k << s0);
+			u32 x;
+			if (mode == LOAD_INPLACE)
+				x = cw[row * cols + col];
+			else {
+				int src = src_row[row];
+				x = src < 0 ? Word<T>::NZ : mode == LOAD_MESSAGE ? (u32)msg[(size_t)src * cols + col] : (u32)cw[row * cols + col];
+			}
+			neg[k] = x & Word<T>::NEG;
+			nz[k] = x & Word<T>::NZ;
+		}
+	}
+#pragma unroll
+	for (int t = 0; t < C; ++t) {
+		if (t < c) {
+#pragma unroll
+			for (int k = 0; k < (1 << C); ++k)
+				if (!(k & (1 << t)) && k + (1 << t) < (1 << c)) {
+					neg[k] ^= neg[k + (1 << t)];
+					nz[k] &= nz[k + (1 << t)];
+				}
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < (1 << C); ++k) {
+		if (k < (1 << c)) {
+			size_t row = row0 + ((size_t)k << s0);
+			u32 m = nz[k] * 0xFFu; // 0xFF where nonzero
+			u32 v = m & (((neg[k] >> 7) * 0xFFu) | Word<T>::NZ);
+			cw[row * cols + col] = (T)v;
+		}
+	}
+}
+
+// dst[r][col] = src[rows[r]][col]
+template <typename T>
+__global__ void __launch_bounds__(256) gather_rows_kernel(T *dst, const T *src, const int *rows, size_t cols)
+{
+	const size_t colblocks = (cols + 255) / 256;
+	const size_t col = (blockIdx.x % colblocks) * 256 + threadIdx.x, r = blockIdx.x / colblocks;
+	if (col < cols)
+		dst[r * cols + col] = src[(size_t)rows[r] * cols + col];
+}
+
+// ---------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------
+
+struct DeviceBuffer {
+	void *p = nullptr;
+	size_t bytes = 0;
+	int reserve(size_t want)
+	{
+		if (want <= bytes)
+			return POLAR_OK;
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+		bytes = 0;
+		HIP_TRY(hipMalloc(&p, want));
+		bytes = want;
+		return POLAR_OK;
+	}
+	void release()
+	{
+		if (p)
+			(void)hipFree(p);
+		p = nullptr;
+		bytes = 0;
+	}
+};
+
+struct LoadedProgram {
+	HostProgram host;
+	DevOp *dev = nullptr;
+};
+
+struct polar_hip_handle {
+	int device = 0;
+	int cus = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	bool timed = false;
+	std::vector<LoadedProgram> programs;
+	DeviceBuffer scratch, stage_in, stage_out, enc_tmp, tables;
+	std::vector<uint8_t> frozen_cache; // frozen set the device tables were built from
+	int cfg_frames_per_wave = 0, cfg_lds_level = 0, cfg_max_waves = 0;
+};
+
+static int use_device(polar_hip_handle *h)
+{
+	HIP_TRY(hipSetDevice(h->device));
+	return POLAR_OK;
+}
+
+extern "C" const char *polar_hip_last_error(void)
+{
+	return g_error.c_str();
+}
+
+// ---- host-side construction ----
+
+extern "C" int polar_code_const0(uint8_t *frozen, int level, int K, long double erasure_probability)
+{
+	if (!frozen || level < 0 || level > MAX_LEVEL || K < 0 || K > (1 << level))
+		return fail(POLAR_E_ARG, "polar_code_const0: bad argument");
+	code_const0(frozen, level, K, erasure_probability);
+	return POLAR_OK;
+}
+
+extern "C" int polar_freezer(uint8_t *frozen, int level, long double erasure_probability, long double freezing_threshold)
+{
+	if (!frozen || level < 0 || level > MAX_LEVEL)
+		return fail(POLAR_E_ARG, "polar_freezer: bad argument");
+	return freezer(frozen, level, erasure_probability, freezing_threshold);
+}
+
+extern "C" int polar_compile(uint8_t *program, const uint8_t *frozen, int level)
+{
+	if (!program || !frozen || level < 1 || level > MAX_LEVEL)
+		return fail(POLAR_E_ARG, "polar_compile: bad argument");
+	ProgramBuilder b;
+	int n = b.run(program, frozen, level);
+	if (n < 0)
+		return fail(POLAR_E_PROGRAM, "polar_compile: an information bit directly left of a frozen bit cannot be compiled (reference asserts level > 0)");
+	return n;
+}
+
+extern "C" int polar_program_rows(const uint8_t *program, int length)
+{
+	if (!program)
+		return fail(POLAR_E_ARG, "polar_program_rows: null program");
+	HostProgram hp;
+	int err = translate_program(program, length, hp);
+	if (err)
+		return fail(POLAR_E_PROGRAM, "malformed program (rule " + std::to_string(err) + ")");
+	return (int)hp.rows;
+}
+
+// ---- device objects ----
+
+extern "C" int polar_hip_create(polar_hip_handle **out, int device)
+{
+	if (!out)
+		return fail(POLAR_E_ARG, "polar_hip_create: null out pointer");
+	*out = nullptr;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+		return fail(POLAR_E_NODEVICE, "polar_hip_create: no HIP device");
+	if (device < 0 || device >= count)
+		return fail(POLAR_E_ARG, "polar_hip_create: device index out of range");
+	hipDeviceProp_t prop;
+	HIP_TRY(hipGetDeviceProperties(&prop, device));
+	if (!strstr(prop.gcnArchName, "gfx950"))
+		return fail(POLAR_E_NODEVICE, std::string("polar_hip_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+	polar_hip_handle *h = new polar_hip_handle;
+	h->device = device;
+	h->cus = prop.multiProcessorCount;
+	HIP_TRY(hipSetDevice(device));
+	HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	HIP_TRY(hipEventCreate(&h->ev0));
+	HIP_TRY(hipEventCreate(&h->ev1));
+	*out = h;
+	return POLAR_OK;
+}
+
+extern "C" void polar_hip_destroy(polar_hip_handle *h)
+{
+	if (!h)
+		return;
+	(void)hipSetDevice(h->device);
+	(void)hipStreamSynchronize(h->stream);
+	for (auto &p : h->programs)
+		if (p.dev)
+			(void)hipFree(p.dev);
+	h->scratch.release();
+	h->stage_in.release();
+	h->stage_out.release();
+	h->enc_tmp.release();
+	h->tables.release();
+	(void)hipEventDestroy(h->ev0);
+	(void)hipEventDestroy(h->ev1);
+	(void)hipStreamDestroy(h->stream);
+	delete h;
+}
+
+extern "C" int polar_hip_configure(polar_hip_handle *h, int frames_per_wave, int lds_level, int max_waves)
+{
+	if (!h)
+		return fail(POLAR_E_ARG, "polar_hip_configure: null handle");
+	if (frames_per_wave || lds_level) {
+		bool found = false;
+		for (const KernelVariant &v : g_variants)
+			found |= 4 * v.q == frames_per_wave && v.rl == lds_level;
+		if (!found)
+			return fail(POLAR_E_ARG, "polar_hip_configure: no kernel built for this (frames_per_wave, lds_level)");
+	}
+	if (max_waves < 0)
+		return fail(POLAR_E_ARG, "polar_hip_configure: negative max_waves");
+	h->cfg_frames_per_wave = frames_per_wave;
+	h->cfg_lds_level = lds_level;
+	h->cfg_max_waves = max_waves;
+	return POLAR_OK;
+}
+
+extern "C" int polar_hip_load_program(polar_hip_handle *h, const uint8_t *program, int length)
+{
+	if (!h || !program)
+		return fail(POLAR_E_ARG, "polar_hip_load_program: null argument");
+	LoadedProgram lp;
+	int err = translate_program(program, length, lp.host);
+	if (err)
+		return fail(POLAR_E_PROGRAM, "polar_hip_load_program: malformed program (rule " + std::to_string(err) + ")");
+	if (use_device(h))
+		return POLAR_E_HIP;
+	size_t bytes = lp.host.ops.size() * sizeof(DevOp);
+	HIP_TRY(hipMalloc((void **)&lp.dev, bytes));
+	HIP_TRY(hipMemcpy(lp.dev, lp.host.ops.data(), bytes, hipMemcpyHostToDevice));
+	h->programs.push_back(lp);
+	return (int)h->programs.size() - 1;
+}
+
+static const KernelVariant *pick_variant(const polar_hip_handle *h, int top)
+{
+	int fpw = h->cfg_frames_per_wave, rl = h->cfg_lds_level;
+	if (!fpw) { // defaults: the ~20 KB family
+		fpw = 16;
+		rl = 9;
+		(void)top;
+	}
+	for (const KernelVariant &v : g_variants)
+		if (4 * v.q == fpw && v.rl == rl)
+			return &v;
+	return nullptr;
+}
+
+static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, hipStream_t stream, bool timed)
+{
+	const LoadedProgram &lp = h->programs[program_id];
+	const KernelVariant *v = pick_variant(h, lp.host.top);
+	if (!v)
+		return fail(POLAR_E_ARG, "no kernel variant for the configured (frames_per_wave, lds_level)");
+	const int fpw = 4 * v->q;
+	size_t groups = (frames + fpw - 1) / fpw;
+	if (groups > 0x7FFFFFFFu)
+		return fail(POLAR_E_ARG, "too many frames for one call");
+	h->timed = false;
+	if (!groups)
+		return POLAR_OK;
+	int per_cu = 0;
+	HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->fn, 64, 0));
+	if (per_cu < 1)
+		return fail(POLAR_E_HIP, "decode kernel does not fit on a CU");
+	size_t blocks = (size_t)per_cu * h->cus;
+	if (h->cfg_max_waves && (size_t)h->cfg_max_waves < blocks)
+		blocks = h->cfg_max_waves;
+	if (groups < blocks)
+		blocks = groups;
+	if (blocks >= 8)
+		blocks -= blocks % 8;
+	DecodeArgs a;
+	a.prog = lp.dev;
+	a.cw = (const uint8_t *)codeword;
+	a.msg = (uint8_t *)message;
+	a.frames = frames;
+	a.groups = (u32)groups;
+	a.top = lp.host.top;
+	a.aligned = ((uintptr_t)codeword % 4 == 0) && ((uintptr_t)message % 4 == 0);
+	a.scratch = nullptr;
+	a.block_dwords = 0;
+	if (lp.host.top > v->rl) {
+		size_t soft = (size_t)v->q << lp.host.top;
+		a.block_dwords = soft + 2 * (soft / 8);
+		int rc = h->scratch.reserve(blocks * a.block_dwords * sizeof(u32));
+		if (rc)
+			return rc;
+		a.scratch = (u32 *)h->scratch.p;
+	}
+	if (timed)
+		HIP_TRY(hipEventRecord(h->ev0, stream));
+	hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64), 0, stream, a);
+	HIP_TRY(hipGetLastError());
+	if (timed) {
+		HIP_TRY(hipEventRecord(h->ev1, stream));
+		h->timed = true;
+	}
+	return POLAR_OK;
+}
+
+static int check_decode_args(polar_hip_handle *h, int program_id, const void *message, const void *codeword, size_t frames)
+{
+	if (!h)
+		return fail(POLAR_E_ARG, "polar_hip_decode: null handle");
+	if (program_id < 0 || (size_t)program_id >= h->programs.size())
+		return fail(POLAR_E_ARG, "polar_hip_decode: unknown program id");
+	if (frames && (!codeword || (!message && h->programs[program_id].host.rows)))
+		return fail(POLAR_E_ARG, "polar_hip_decode: null buffer");
+	return POLAR_OK;
+}
+
+extern "C" int polar_hip_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, int where)
+{
+	int rc = check_decode_args(h, program_id, message, codeword, frames);
+	if (rc)
+		return rc;
+	if (where != POLAR_HOST && where != POLAR_DEVICE)
+		return fail(POLAR_E_ARG, "polar_hip_decode: bad `where`");
+	if ((rc = use_device(h)))
+		return rc;
+	if (!frames)
+		return POLAR_OK;
+	const HostProgram &hp = h->programs[program_id].host;
+	if (where == POLAR_DEVICE) {
+		if ((rc = launch_decode(h, program_id, message, codeword, frames, h->stream, true)))
+			return rc;
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		return POLAR_OK;
+	}
+	size_t in_bytes = ((size_t)1 << hp.top) * frames, out_bytes = (size_t)hp.rows * frames;
+	if ((rc = h->stage_in.reserve(in_bytes)) || (rc = h->stage_out.reserve(out_bytes ? out_bytes : 4)))
+		return rc;
+	HIP_TRY(hipMemcpyAsync(h->stage_in.p, codeword, in_bytes, hipMemcpyHostToDevice, h->stream));
+	if ((rc = launch_decode(h, program_id, (int8_t *)h->stage_out.p, (const int8_t *)h->stage_in.p, frames, h->stream, true)))
+		return rc;
+	if (out_bytes)
+		HIP_TRY(hipMemcpyAsync(message, h->stage_out.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return POLAR_OK;
+}
+
+extern "C" int polar_hip_decode_async(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, void *stream)
+{
+	int rc = check_decode_args(h, program_id, message, codeword, frames);
+	if (rc)
+		return rc;
+	if ((rc = use_device(h)))
+		return rc;
+	return launch_decode(h, program_id, message, codeword, frames, (hipStream_t)stream, false);
+}
+
+extern "C" float polar_hip_last_decode_ms(polar_hip_handle *h)
+{
+	if (!h || !h->timed)
+		return (float)fail(POLAR_E_ARG, "polar_hip_last_decode_ms: no timed decode on this handle");
+	float ms = 0;
+	if (hipEventSynchronize(h->ev1) != hipSuccess || hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess)
+		return (float)fail(POLAR_E_HIP, "polar_hip_last_decode_ms: event query failed");
+	return ms;
+}
+
+extern "C" int polar_hip_synchronize(polar_hip_handle *h)
+{
+	if (!h)
+		return fail(POLAR_E_ARG, "polar_hip_synchronize: null handle");
+	int rc = use_device(h);
+	if (rc)
+		return rc;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return POLAR_OK;
+}
+
+// ---- encoders ----
+
+// device tables for a frozen set: src_row[N] (message row per position or -1) then info_pos[K]
+static int upload_tables(polar_hip_handle *h, const uint8_t *frozen, int level, int *K_out)
+{
+	size_t n = (size_t)1 << level;
+	std::vector<int> t(2 * n);
+	int k = 0;
+	for (size_t i = 0; i < n; ++i) {
+		if (frozen[i])
+			t[i] = -1;
+		else {
+			t[n + k] = (int)i;
+			t[i] = k++;
+		}
+	}
+	*K_out = k;
+	if (h->frozen_cache.size() == n && !memcmp(h->frozen_cache.data(), frozen, n) && h->tables.p)
+		return POLAR_OK;
+	int rc = h->tables.reserve(2 * n * sizeof(int));
+	if (rc)
+		return rc;
+	h->frozen_cache.clear();
+	HIP_TRY(hipMemcpyAsync(h->tables.p, t.data(), 2 * n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream)); // `t` goes out of scope
+	h->frozen_cache.assign(frozen, frozen + n);
+	return POLAR_OK;
+}
+
+static const int BFLY_C = 4;
+
+template <typename T>
+static int transform_passes(polar_hip_handle *h, T *cw, const T *msg, const int *src_row, size_t cols, int level, int first_mode)
+{
+	int mode = first_mode;
+	for (int s0 = 0; s0 < level; s0 += BFLY_C) {
+		int c = level - s0 < BFLY_C ? level - s0 : BFLY_C;
+		size_t blocks = (((size_t)1 << level) >> c) * ((cols + 255) / 256);
+		if (blocks > 0x7FFFFFFFu)
+			return fail(POLAR_E_ARG, "polar_hip_encode: too many frames for one call");
+		hipLaunchKernelGGL((butterfly_kernel<T, BFLY_C>), dim3((unsigned)blocks), dim3(256), 0, h->stream, cw, msg, src_row, cols, level, s0, mode);
+		HIP_TRY(hipGetLastError());
+		mode = LOAD_INPLACE;
+	}
+	return POLAR_OK;
+}
+
+// codeword (device, N x frames) <- encode(message (device, K x frames))
+static int encode_device(polar_hip_handle *h, int systematic, int8_t *cw, const int8_t *msg, int level, size_t frames)
+{
+	const int *src_row = (const int *)h->tables.p;
+	bool wide = frames % 4 == 0 && (uintptr_t)cw % 4 == 0 && (uintptr_t)msg % 4 == 0;
+	int rc;
+	for (int round = 0; round <= (systematic ? 1 : 0); ++round) {
+		int mode = round ? LOAD_REFREEZE : LOAD_MESSAGE;
+		if (wide)
+			rc = transform_passes<u32>(h, (u32 *)cw, (const u32 *)msg, src_row, frames / 4, level, mode);
+		else
+			rc = transform_passes<uint8_t>(h, (uint8_t *)cw, (const uint8_t *)msg, src_row, frames, level, mode);
+		if (rc)
+			return rc;
+	}
+	return POLAR_OK;
+}
+
+extern "C" int polar_hip_encode(polar_hip_handle *h, int systematic, int8_t *codeword, const int8_t *message, const uint8_t *frozen, int level, size_t frames, int where)
+{
+	if (!h || !frozen || level < 1 || level > MAX_LEVEL || (where != POLAR_HOST && where != POLAR_DEVICE))
+		return fail(POLAR_E_ARG, "polar_hip_encode: bad argument");
+	if (frames && !codeword)
+		return fail(POLAR_E_ARG, "polar_hip_encode: null codeword");
+	int rc = use_device(h), K = 0;
+	if (rc)
+		return rc;
+	if (!frames)
+		return POLAR_OK;
+	if ((rc = upload_tables(h, frozen, level, &K)))
+		return rc;
+	if (K && !message)
+		return fail(POLAR_E_ARG, "polar_hip_encode: null message");
+	size_t n = (size_t)1 << level;
+	if (where == POLAR_DEVICE) {
+		if ((rc = encode_device(h, systematic, codeword, message, level, frames)))
+			return rc;
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		return POLAR_OK;
+	}
+	if ((rc = h->stage_in.reserve(n * frames)) || (rc = h->stage_out.reserve((size_t)(K ? K : 1) * frames)))
+		return rc;
+	if (K)
+		HIP_TRY(hipMemcpyAsync(h->stage_out.p, message, (size_t)K * frames, hipMemcpyHostToDevice, h->stream));
+	if ((rc = encode_device(h, systematic, (int8_t *)h->stage_in.p, (const int8_t *)h->stage_out.p, level, frames)))
+		return rc;
+	HIP_TRY(hipMemcpyAsync(codeword, h->stage_in.p, n * frames, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return POLAR_OK;
+}
+
+extern "C" int polar_hip_systematic_extract(polar_hip_handle *h, int8_t *decoded, const uint8_t *frozen, int level, size_t frames, int where)
+{
+	if (!h || !frozen || level < 1 || level > MAX_LEVEL || (where != POLAR_HOST && where != POLAR_DEVICE))
+		return fail(POLAR_E_ARG, "polar_hip_systematic_extract: bad argument");
+	int rc = use_device(h), K = 0;
+	if (rc)
+		return rc;
+	if (!frames)
+		return POLAR_OK;
+	if ((rc = upload_tables(h, frozen, level, &K)))
+		return rc;
+	if (!K)
+		return POLAR_OK;
+	if (!decoded)
+		return fail(POLAR_E_ARG, "polar_hip_systematic_extract: null buffer");
+	size_t n = (size_t)1 << level;
+	if ((rc = h->enc_tmp.reserve(n * frames)))
+		return rc;
+	int8_t *dev = decoded;
+	if (where == POLAR_HOST) {
+		if ((rc = h->stage_out.reserve((size_t)K * frames)))
+			return rc;
+		dev = (int8_t *)h->stage_out.p;
+		HIP_TRY(hipMemcpyAsync(dev, decoded, (size_t)K * frames, hipMemcpyHostToDevice, h->stream));
+	}
+	if ((rc = encode_device(h, 0, (int8_t *)h->enc_tmp.p, dev, level, frames)))
+		return rc;
+	const int *info_pos = (const int *)h->tables.p + n;
+	bool wide = frames % 4 == 0 && (uintptr_t)dev % 4 == 0;
+	size_t cols = wide ? frames / 4 : frames, blocks = (size_t)K * ((cols + 255) / 256);
+	if (blocks > 0x7FFFFFFFu)
+		return fail(POLAR_E_ARG, "polar_hip_systematic_extract: too many frames for one call");
+	if (wide)
+		hipLaunchKernelGGL(gather_rows_kernel<u32>, dim3((unsigned)blocks), dim3(256), 0, h->stream, (u32 *)dev, (const u32 *)h->enc_tmp.p, info_pos, cols);
+	else
+		hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, h->stream, (uint8_t *)dev, (const uint8_t *)h->enc_tmp.p, info_pos, cols);
+	HIP_TRY(hipGetLastError());
+	if (where == POLAR_HOST)
+		HIP_TRY(hipMemcpyAsync(decoded, dev, (size_t)K * frames, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return POLAR_OK;
+}

@@ -1,0 +1,109 @@
+// program.hpp -- host-side translation of the reference's byte-code (polar_compiler.hh:51-58,
+// executed by polar_decoder.hh:131-464) into the device instruction stream of sc_core.hpp.
+//
+// The reference interpreter keeps three running values while it walks the program -- the
+// current level `lvl`, the partial-sum cursor `hrd` and the message cursor `msg`
+// (polar_decoder.hh:133-134, updated at :140, :203, :204, :299, :331, :363, :364, :395, :396,
+// :428, :459). They depend only on the program, so they are resolved here once per loaded
+// program and the kernel reads them from constant memory instead of recomputing them.
+#pragma once
+
+#include <stdint.h>
+#include <vector>
+
+#include "sc_core.hpp"
+
+namespace polar {
+
+struct HostProgram {
+	int top = 0;        // level of the code, N = 1 << top
+	uint32_t rows = 0;  // message symbols emitted per frame (K for a compiled frozen set)
+	std::vector<DevOp> ops; // terminated by OP_END
+};
+
+enum { MAX_LEVEL = 24 };
+
+// Returns 0 on success. A nonzero return marks a program on which the reference would trip
+// one of its asserts (polar_decoder.hh:135, :170, :202, :463 ...) or run outside its arrays.
+inline int translate_program(const uint8_t *prog, int length, HostProgram &out)
+{
+	if (length < 2)
+		return 1;
+	int top = prog[0];
+	if (top < 1 || top > MAX_LEVEL)
+		return 2;
+	int lvl = top;
+	uint32_t n = 1u << top, hrd = 0, row = 0;
+	out.top = top;
+	out.ops.clear();
+	int pc = 1;
+	for (;; ++pc) {
+		if (pc >= length)
+			return 3; // no terminator
+		uint32_t op = prog[pc];
+		if (op == OP_END)
+			break;
+		DevOp d = {0, 0, 0, 0};
+		switch (op) {
+		case OP_LEFT:
+		case OP_RATE0_RIGHT:
+			if (lvl < 2)
+				return 4;
+			d.op_level = op | (uint32_t)lvl << 8;
+			--lvl;
+			if (op == OP_RATE0_RIGHT)
+				hrd += 1u << lvl;
+			break;
+		case OP_RIGHT:
+			if (lvl + 1 > top)
+				return 5;
+			d.op_level = op | (uint32_t)(lvl + 1) << 8;
+			d.hrd = hrd; // the decided left child
+			hrd += 1u << lvl;
+			break;
+		case OP_COMB:
+		case OP_RATE0_COMB:
+			if (lvl + 1 > top || hrd < (1u << lvl))
+				return 6;
+			hrd -= 1u << lvl;
+			++lvl;
+			d.op_level = op | (uint32_t)lvl << 8;
+			d.hrd = hrd;
+			break;
+		case OP_RATE1_COMB:
+			if (lvl + 1 > top)
+				return 7;
+			++lvl;
+			d.op_level = op | (uint32_t)lvl << 8;
+			d.hrd = hrd;
+			d.row = row;
+			row += 1u << (lvl - 1);
+			break;
+		case OP_RATE0:
+		case OP_RATE1:
+		case OP_REP:
+		case OP_SPC:
+			d.op_level = op | (uint32_t)lvl << 8;
+			d.hrd = hrd;
+			d.row = row;
+			row += op == OP_RATE1 ? 1u << lvl : op == OP_REP ? 1u : op == OP_SPC ? (1u << lvl) - 1 : 0u;
+			break;
+		default:
+			return 8;
+		}
+		int node = (int)(d.op_level >> 8);
+		// the node must sit on its natural boundary inside the code
+		if (d.hrd & ((1u << node) - 1) || d.hrd + (1u << node) > n || row > n)
+			if (op != OP_LEFT && op != OP_RATE0_RIGHT)
+				return 9;
+		out.ops.push_back(d);
+	}
+	if (lvl != top)
+		return 10;
+	DevOp e = {OP_END, 0, 0, 0};
+	out.ops.push_back(e);
+	out.rows = row;
+	return 0;
+}
+
+} // namespace polar

@@ -1,0 +1,622 @@
+// sc_core.hpp -- wavefront-level successive-cancellation decoder core for gfx950 (MI355X).
+//
+// One 64-lane wavefront owns a GROUP of G = 4*Q codewords (frames) and interprets the
+// reference's node program (polar_compiler.hh:11-13 opcodes) for all of them in lock-step.
+//
+// Data layout ("frame-packed"): one dword carries the same code element of 4 consecutive
+// frames (one int8 LLR per byte), exactly the bytes of the reference's element-major /
+// frame-minor buffers (testbench.cc:134-139), so input rows and message rows move as whole
+// dwords with no transposition. A level-l LLR vector of the group is the linear dword array
+//        v[i*Q + q]     i = element 0..2^l-1, q = frame quad 0..Q-1
+// stored at dword offset Q*2^l of the group's soft arena -- the reference's soft[] indexing
+// (polar_decoder.hh:128) scaled by Q. Levels <= RL live in LDS, levels RL+1..top-1 in a
+// per-wave HBM scratch arena (coalesced 16-byte accesses), level `top` is the caller's input.
+// Every node function of polar_decoder.hh:28-127 therefore becomes an element-wise pass
+// over linear arrays with all 64 lanes busy whenever Q*2^(l-1) >= 64.
+//
+// Arithmetic: packed 16-bit VALU ops. A dword is split into two 2xi16 registers holding
+// the int8 values in the HIGH byte of each half ("scaled by 256"): v_pk_add_i16/v_pk_sub_i16
+// with clamp then saturate exactly like int8 (vqadd, simd.hh:1120-1127), -(-128) saturates
+// to +127 (vqabs, simd.hh:292-299), and v_perm_b32 splits / re-interleaves the bytes.
+//
+// Partial sums ("hard", values in {-1,0,+1}, polar_decoder.hh:129) are kept as two bit
+// planes (sign, zero). Eight consecutive elements share one dword per frame quad:
+//        bit (8*k + 7 - j)  <->  element 8*o + j of frame 4*q + k     (plane dword o*Q + q)
+// so `plane << j` puts element j's bits of the 4 frames on the byte sign bits, where
+// v_perm_b32's sign-replicating selectors turn them into 16-bit lane masks.
+//
+// This header is compiled for the device by polar_hip.hip. tests/emu/ compiles the same text
+// for the host with POLAR_EMU defined (lanes run one after another inside PFOR_LANES) so the
+// bit tricks can be unit-tested without a GPU; the product never uses that build.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+namespace polar {
+
+typedef uint32_t u32;
+
+enum : u32 {
+	OP_LEFT = 0, OP_RIGHT = 1, OP_COMB = 2, OP_RATE0 = 3, OP_RATE1 = 4, OP_REP = 5, OP_SPC = 6,
+	OP_RATE0_RIGHT = 7, OP_RATE0_COMB = 8, OP_RATE1_COMB = 9, OP_END = 255
+};
+
+// Device instruction word: the reference byte-code with the interpreter's running state
+// (lvl / hrd / msg of polar_decoder.hh:133-134) resolved at load time by the host.
+struct DevOp {
+	u32 op_level; // opcode | node level << 8
+	u32 hrd;      // absolute position of the node in the partial-sum array
+	u32 row;      // first message row the node emits
+	u32 pad;
+};
+
+#ifndef POLAR_EMU
+#define PDEV __device__ __forceinline__
+#define PFOR_LANES(lane) for (int lane = (int)(threadIdx.x & 63), once_ = 1; once_; once_ = 0)
+typedef short v2s_ __attribute__((ext_vector_type(2)));
+struct alignas(16) u32x4 { u32 x, y, z, w; };
+PDEV u32 pk_add_sat(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_add_sat(__builtin_bit_cast(v2s_, a), __builtin_bit_cast(v2s_, b))); }
+PDEV u32 pk_sub_sat(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2s_, a), __builtin_bit_cast(v2s_, b))); }
+PDEV u32 pk_min(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(v2s_, a), __builtin_bit_cast(v2s_, b))); }
+PDEV u32 pk_max(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(v2s_, a), __builtin_bit_cast(v2s_, b))); }
+PDEV u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+// all lanes of the wave have executed everything before this point, LDS and scratch writes
+// of one lane are visible to the others: a single wavefront executes its DS / VMEM
+// instructions in order, so only the compiler has to be kept from reordering.
+PDEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+#endif
+
+PDEV u32 bfi(u32 mask, u32 a, u32 b) { return ((a ^ b) & mask) ^ b; } // mask ? a : b (v_bfi_b32)
+
+// ---- packed int8 arithmetic (PolarHelper<SIMD<int8_t,W>>, polar_helper.hh:113-173) ----
+
+static const u32 HI_MASK = 0xFF00FF00u;
+static const u32 SIGN_BITS = 0x80808080u;
+PDEV u32 split_hi(u32 a) { return a & HI_MASK; }                 // bytes 1,3 stay in the high bytes
+PDEV u32 split_lo(u32 a) { return perm(a, a, 0x020C000Cu); }     // bytes 0,2 -> high bytes, zero fill
+PDEV u32 merge(u32 hi, u32 lo) { return perm(hi, lo, 0x07030501u); } // high bytes -> b3=hi.3 b2=lo.3 b1=hi.1 b0=lo.1
+
+// prod (polar_helper.hh:153-160) on one 2xi16 register: sgn(x)sgn(y)min(|x|,|y|) = max(min(x,y), min(-x,-y));
+// the saturating negation maps -128 to +127 like vqabs.
+PDEV u32 prod_half(u32 x, u32 y)
+{
+	u32 nx = pk_sub_sat(0, x), ny = pk_sub_sat(0, y);
+	return pk_max(pk_min(x, y), pk_min(nx, ny));
+}
+PDEV u32 prod4(u32 a, u32 b)
+{
+	return merge(prod_half(split_hi(a), split_hi(b)), prod_half(split_lo(a), split_lo(b)));
+}
+// qadd (polar_helper.hh:141-144)
+PDEV u32 qadd4(u32 a, u32 b)
+{
+	return merge(pk_add_sat(split_hi(a), split_hi(b)), pk_add_sat(split_lo(a), split_lo(b)));
+}
+// 16-bit lane masks from sign bits: m_hi from bits 15/31, m_lo from bits 7/23
+PDEV u32 mask_hi(u32 s) { return perm(s, s, 0x09090808u); }
+PDEV u32 mask_lo(u32 s) { u32 t = s << 8; return perm(t, t, 0x09090808u); }
+// madd (polar_helper.hh:161-168): vqadd(vsign(vmax(a,-127), h), b); hs / hz carry the sign and
+// zero bits of h on the byte sign bits (other bits are ignored).
+PDEV u32 madd4(u32 hs, u32 hz, u32 a, u32 b)
+{
+	const u32 K = 0x81008100u; // -127 * 256 per half
+	u32 ah = pk_max(split_hi(a), K), al = pk_max(split_lo(a), K);
+	u32 bh = split_hi(b), bl = split_lo(b);
+	u32 rh = bfi(mask_hi(hs), pk_sub_sat(bh, ah), pk_add_sat(bh, ah));
+	u32 rl = bfi(mask_lo(hs), pk_sub_sat(bl, al), pk_add_sat(bl, al));
+	rh = bfi(mask_hi(hz), bh, rh);
+	rl = bfi(mask_lo(hz), bl, rl);
+	return merge(rh, rl);
+}
+// bit 7 of every byte that equals zero
+PDEV u32 zero_bytes(u32 x)
+{
+	u32 t = (x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;
+	return ~(t | x) & SIGN_BITS;
+}
+// byte masks 0xFF / 0x00 from bit 7 of every byte
+PDEV u32 byte_mask(u32 s) { return ((s & SIGN_BITS) >> 7) * 0xFFu; }
+// message symbols (+1 / -1 / 0 per byte) from sign and zero bits on the byte sign bits
+PDEV u32 symbols(u32 s, u32 z) { return (byte_mask(s) | 0x01010101u) & ~byte_mask(z); }
+// |x| of the scaled halves, low bytes cleared (vqabs)
+PDEV u32 abs_half(u32 x) { return pk_max(x, pk_sub_sat(0, x)) & HI_MASK; }
+// bits 15/31 where the (low-byte-clean) halves are equal
+PDEV u32 eq_half(u32 x, u32 y)
+{
+	u32 d = x ^ y;
+	u32 t = (d & 0x7FFF7FFFu) + 0x7FFF7FFFu;
+	return ~(t | d) & 0x80008000u;
+}
+
+// ---- memory views ----
+
+struct Vec { // linear dword array in LDS or HBM scratch
+	u32 *p;
+	PDEV u32 ld(int t) const { return p[t]; }
+	PDEV void st(int t, u32 v) const { p[t] = v; }
+	PDEV u32x4 ld4(int t) const { return *reinterpret_cast<const u32x4 *>(p + t); }
+	PDEV void st4(int t, u32x4 v) const { *reinterpret_cast<u32x4 *>(p + t) = v; }
+};
+
+// the caller's codeword buffer: row i of the group starts at in + i*stride (bytes)
+template <int Q> struct InVec {
+	const uint8_t *p; // first byte of the group's frames in row 0
+	size_t stride;    // total frames (bytes per row)
+	int valid;        // frames of this group that exist (<= 4*Q)
+	bool fast;        // rows dword-aligned and group complete
+	PDEV u32 ld(int t) const
+	{
+		int i = t / Q, q = t % Q;
+		const uint8_t *r = p + (size_t)i * stride + 4 * q;
+		if (fast)
+			return *reinterpret_cast<const u32 *>(r);
+		u32 v = 0;
+		for (int k = 0; k < 4; ++k)
+			if (4 * q + k < valid)
+				v |= (u32)r[k] << (8 * k);
+		return v;
+	}
+	PDEV u32x4 ld4(int t) const
+	{
+		u32x4 v;
+		v.x = ld(t); v.y = ld(t + 1); v.z = ld(t + 2); v.w = ld(t + 3);
+		return v;
+	}
+};
+
+template <int Q> struct OutRows { // the caller's message buffer, same row layout
+	uint8_t *p;
+	size_t stride;
+	int valid;
+	bool fast;
+	PDEV void st(u32 row, int q, u32 v) const
+	{
+		uint8_t *r = p + (size_t)row * stride + 4 * q;
+		if (fast) {
+			*reinterpret_cast<u32 *>(r) = v;
+			return;
+		}
+		for (int k = 0; k < 4; ++k)
+			if (4 * q + k < valid)
+				r[k] = (uint8_t)(v >> (8 * k));
+	}
+};
+
+// d[t] = fn(t, a[t], a[t + n]) for t < n: the shape of left / right / rate0_right and of the
+// halving steps of rep (polar_decoder.hh:28-51, 99-101)
+template <class A, class D, class Fn>
+PDEV void ew_pairs(const A &a, const D &d, int n, Fn fn)
+{
+	if (n >= 256) {
+		PFOR_LANES(lane) {
+			for (int t = lane * 4; t < n; t += 256) {
+				u32x4 x = a.ld4(t), y = a.ld4(t + n), r;
+				r.x = fn(t, x.x, y.x);
+				r.y = fn(t + 1, x.y, y.y);
+				r.z = fn(t + 2, x.z, y.z);
+				r.w = fn(t + 3, x.w, y.w);
+				d.st4(t, r);
+			}
+		}
+	} else {
+		PFOR_LANES(lane) {
+			for (int t = lane; t < n; t += 64)
+				d.st(t, fn(t, a.ld(t), a.ld(t + n)));
+		}
+	}
+	wave_sync();
+}
+
+// One group's decoder state.
+template <int Q, int RL>
+struct Group {
+	static_assert(RL >= 4, "nodes that share a partial-sum octet must live in LDS");
+	static const int W = 1 << (RL + 1); // elements of the LDS partial-sum window
+	static const int LDS_SOFT = Q << (RL + 1), LDS_PLANE = (W / 8) * Q, LDS_TMP = 8 * Q;
+	static const int LDS_DWORDS = LDS_SOFT + 2 * LDS_PLANE + LDS_TMP;
+	u32 *sl;        // LDS soft arena, LDS_SOFT dwords (level l at Q << l)
+	u32 *hls, *hlz; // LDS partial-sum planes (sign, zero), LDS_PLANE dwords each, index by position mod W
+	u32 *tl;        // LDS scratch for nodes smaller than one octet, LDS_TMP dwords
+	u32 *sg;        // scratch soft arena, Q << top dwords
+	u32 *hgs, *hgz; // scratch partial-sum planes, (Q << top) / 8 dwords each
+	InVec<Q> in;
+	OutRows<Q> out;
+	int top;
+
+	// plane index / shift of element e of a node whose first element sits at position eb
+	static PDEV int pidx(u32 e, int q) { return (int)(e >> 3) * Q + q; }
+
+	// ---- f / g / qadd passes: polar_decoder.hh:28-51 ----
+	template <class A, class D>
+	PDEV void pass_left(const A &a, const D &d, int n)
+	{
+		ew_pairs(a, d, n, [](int, u32 x, u32 y) { return prod4(x, y); });
+	}
+	template <class A, class D>
+	PDEV void pass_qadd(const A &a, const D &d, int n)
+	{
+		ew_pairs(a, d, n, [](int, u32 x, u32 y) { return qadd4(x, y); });
+	}
+	template <class A, class D>
+	PDEV void pass_right(const A &a, const D &d, int n, const u32 *hs, const u32 *hz, u32 eb)
+	{
+		ew_pairs(a, d, n, [=](int t, u32 x, u32 y) {
+			u32 e = eb + (u32)(t / Q);
+			int i = pidx(e, t % Q), sh = (int)(e & 7);
+			return madd4(hs[i] << sh, hz[i] << sh, x, y);
+		});
+	}
+	// dispatch on where level `lvl` (source) and lvl-1 (destination) live
+	template <int KIND>
+	PDEV void soft_pass(int lvl, u32 hrd)
+	{
+		int n = Q << (lvl - 1);
+		bool dst_lds = lvl - 1 <= RL;
+		u32 eb = dst_lds ? (hrd & (W - 1)) : hrd;
+#define POLAR_RUN(A, D, HS, HZ) \
+		do { \
+			if (KIND == 0) pass_left(A, D, n); \
+			else if (KIND == 1) pass_right(A, D, n, HS, HZ, eb); \
+			else pass_qadd(A, D, n); \
+		} while (0)
+		if (lvl == top) {
+			if (dst_lds)
+				POLAR_RUN(in, (Vec{sl + n}), hls, hlz);
+			else
+				POLAR_RUN(in, (Vec{sg + n}), hgs, hgz);
+		} else if (lvl > RL) {
+			if (dst_lds)
+				POLAR_RUN((Vec{sg + 2 * n}), (Vec{sl + n}), hls, hlz);
+			else
+				POLAR_RUN((Vec{sg + 2 * n}), (Vec{sg + n}), hgs, hgz);
+		} else {
+			POLAR_RUN((Vec{sl + 2 * n}), (Vec{sl + n}), hls, hlz);
+		}
+#undef POLAR_RUN
+	}
+
+	// ---- generic (flat-pointer) accessors for the rarer node types ----
+	PDEV u32 soft_ld(int lvl, int i, int q) const
+	{
+		int t = i * Q + q;
+		if (lvl == top)
+			return in.ld(t);
+		if (lvl > RL)
+			return sg[(Q << lvl) + t];
+		return sl[(Q << lvl) + t];
+	}
+	struct Planes {
+		u32 *s, *z; // flat pointers
+		u32 eb;     // position of the node's first element inside the planes
+	};
+	PDEV Planes planes(int node_level, u32 hrd) const
+	{
+		Planes p;
+		if (node_level <= RL) {
+			p.s = hls; p.z = hlz; p.eb = hrd & (W - 1);
+		} else {
+			p.s = hgs; p.z = hgz; p.eb = hrd;
+		}
+		return p;
+	}
+	// byte-replicated mask of the `len` (< 8) elements starting at octet offset j0
+	static PDEV u32 span_mask(int j0, int len)
+	{
+		u32 b = (0xFFu >> j0) & ~(0xFFu >> (j0 + len));
+		return b * 0x01010101u;
+	}
+	// scratch below the node's own level (dead at a leaf, polar_decoder.hh:118): flat pointer to
+	// the level-`lvl` region, `lvl` < node level
+	PDEV u32 *tmp_region(int lvl) const
+	{
+		if (lvl > RL)
+			return sg + (Q << lvl);
+		return sl + (Q << lvl);
+	}
+	// scratch for a leaf-like node of `len` elements at level `lvl`: at least 4*max(1,len/8)*Q dwords
+	PDEV u32 *node_tmp(int lvl, int len) const { return len >= 8 ? tmp_region(lvl - 1) : tl; }
+
+	// comb / rate0_comb (polar_decoder.hh:52-67): node of level lvl at hrd; RATE0: left half is all +1
+	template <bool RATE0>
+	PDEV void comb(int lvl, u32 hrd)
+	{
+		int h = 1 << (lvl - 1);
+		Planes c = planes(lvl - 1, hrd), o = planes(lvl, hrd);
+		if (h < 8) { // both halves share one octet (always in LDS: lvl <= 3)
+			int j0 = (int)(o.eb & 7);
+			u32 lowm = span_mask(j0, h);
+			PFOR_LANES(lane) {
+				if (lane < Q) {
+					int i = pidx(o.eb, lane);
+					u32 s = o.s[i], z = o.z[i];
+					if (RATE0) {
+						s = bfi(lowm, s << h, s);
+						z = bfi(lowm, z << h, z);
+					} else {
+						s ^= (s << h) & lowm;
+						z |= (z << h) & lowm;
+					}
+					o.s[i] = s;
+					o.z[i] = z;
+				}
+			}
+		} else {
+			int n = (h >> 3) * Q; // plane dwords per half
+			bool inplace = (lvl - 1 <= RL) == (lvl <= RL);
+			PFOR_LANES(lane) {
+				for (int t = lane; t < n; t += 64) {
+					int il = pidx(c.eb, 0) + t, ir = pidx(c.eb + h, 0) + t;
+					int ol = pidx(o.eb, 0) + t, orr = pidx(o.eb + h, 0) + t;
+					u32 rs = c.s[ir], rz = c.z[ir];
+					if (RATE0) {
+						o.s[ol] = rs;
+						o.z[ol] = rz;
+					} else {
+						o.s[ol] = c.s[il] ^ rs;
+						o.z[ol] = c.z[il] | rz;
+					}
+					if (!inplace) {
+						o.s[orr] = rs;
+						o.z[orr] = rz;
+					}
+				}
+			}
+		}
+		wave_sync();
+	}
+
+	// polar transform of a node's decisions (trans, polar_decoder.hh:15-27) on bit planes held in
+	// ts / tz (nOct*Q dwords each, element 0 at bit 7), then emission of elements first..len-1
+	// as message rows row, row+1, ...
+	PDEV void trans_emit(u32 *ts, u32 *tz, int len, int first, u32 row)
+	{
+		int noct = len >= 8 ? len >> 3 : 1;
+		int n = noct * Q;
+		PFOR_LANES(lane) {
+			for (int t = lane; t < n; t += 64) {
+				u32 s = ts[t], z = tz[t];
+				if (len > 1) { s ^= (s << 1) & 0xAAAAAAAAu; z |= (z << 1) & 0xAAAAAAAAu; }
+				if (len > 2) { s ^= (s << 2) & 0xCCCCCCCCu; z |= (z << 2) & 0xCCCCCCCCu; }
+				if (len > 4) { s ^= (s << 4) & 0xF0F0F0F0u; z |= (z << 4) & 0xF0F0F0F0u; }
+				ts[t] = s;
+				tz[t] = z;
+			}
+		}
+		wave_sync();
+		for (int ho = 1; ho < noct; ho *= 2) { // stages h = 8*ho
+			PFOR_LANES(lane) {
+				for (int t = lane; t < n / 2; t += 64) {
+					int o = t / Q, q = t % Q;
+					int lo = ((o / ho) * 2 * ho + (o % ho)) * Q + q, hi = lo + ho * Q;
+					ts[lo] ^= ts[hi];
+					tz[lo] |= tz[hi];
+				}
+			}
+			wave_sync();
+		}
+		int cnt = (len - first) * Q;
+		PFOR_LANES(lane) {
+			for (int t = lane; t < cnt; t += 64) {
+				int e = first + t / Q, q = t % Q;
+				int i = pidx((u32)e, q), sh = e & 7;
+				out.st(row + (u32)(e - first), q, symbols(ts[i] << sh, tz[i] << sh));
+			}
+		}
+		wave_sync();
+	}
+
+	// store a node's decision bits; s / z hold element j of the item at bit 7-j (normalised)
+	static PDEV void put_bits(const Planes &p, int i, int j0, int len, u32 s, u32 z)
+	{
+		if (len >= 8) {
+			p.s[i] = s;
+			p.z[i] = z;
+		} else {
+			u32 m = span_mask(j0, len);
+			p.s[i] = bfi(m, s >> j0, p.s[i]);
+			p.z[i] = bfi(m, z >> j0, p.z[i]);
+		}
+	}
+
+	// rate0 (polar_decoder.hh:68-75)
+	PDEV void rate0(int lvl, u32 hrd)
+	{
+		int len = 1 << lvl;
+		Planes p = planes(lvl, hrd);
+		int noct = len >= 8 ? len >> 3 : 1, j0 = (int)(p.eb & 7);
+		PFOR_LANES(lane) {
+			for (int t = lane; t < noct * Q; t += 64)
+				put_bits(p, pidx(p.eb, 0) + t, j0, len, 0, 0);
+		}
+		wave_sync();
+	}
+
+	// rate1 (polar_decoder.hh:85-93)
+	PDEV void rate1(int lvl, u32 hrd, u32 row)
+	{
+		int len = 1 << lvl;
+		Planes p = planes(lvl, hrd);
+		int noct = len >= 8 ? len >> 3 : 1, per = len >= 8 ? 8 : len, j0 = (int)(p.eb & 7);
+		u32 *ts = node_tmp(lvl, len), *tz = ts + noct * Q;
+		PFOR_LANES(lane) {
+			for (int t = lane; t < noct * Q; t += 64) {
+				int o = t / Q, q = t % Q;
+				u32 s = 0, z = 0;
+				for (int j = 0; j < per; ++j) {
+					u32 x = soft_ld(lvl, 8 * o + j, q);
+					s |= (x & SIGN_BITS) >> j;
+					z |= zero_bytes(x) >> j;
+				}
+				put_bits(p, pidx(p.eb, 0) + t, j0, len, s, z);
+				ts[t] = s;
+				tz[t] = z;
+			}
+		}
+		wave_sync();
+		trans_emit(ts, tz, len, 0, row);
+	}
+
+	// rep (polar_decoder.hh:94-106)
+	PDEV void rep(int lvl, u32 hrd, u32 row)
+	{
+		for (int l = lvl; l >= 1; --l)
+			soft_pass<2>(l, 0);
+		int len = 1 << lvl;
+		Planes p = planes(lvl, hrd);
+		int noct = len >= 8 ? len >> 3 : 1, j0 = (int)(p.eb & 7);
+		const u32 *s0 = tmp_region(0);
+		PFOR_LANES(lane) {
+			for (int t = lane; t < noct * Q; t += 64) {
+				int o = t / Q, q = t % Q;
+				u32 x = s0[q];
+				u32 s = byte_mask(x), z = byte_mask(zero_bytes(x));
+				put_bits(p, pidx(p.eb, 0) + t, j0, len, s, z);
+				if (o == 0)
+					out.st(row, q, symbols(x, zero_bytes(x)));
+			}
+		}
+		wave_sync();
+	}
+
+	// spc (polar_decoder.hh:107-127)
+	PDEV void spc(int lvl, u32 hrd, u32 row)
+	{
+		int len = 1 << lvl;
+		Planes p = planes(lvl, hrd);
+		int noct = len >= 8 ? len >> 3 : 1, per = len >= 8 ? 8 : len, j0 = (int)(p.eb & 7);
+		int n = noct * Q;
+		// scratch: per-item minima (2 dwords each), then the transform planes; per-quad results in tl
+		u32 *mins = node_tmp(lvl, len);
+		u32 *ts = mins + 2 * n, *tz = ts + n;
+		u32 *wk = tl + 4 * Q; // 3 dwords per quad
+		PFOR_LANES(lane) {
+			for (int t = lane; t < n; t += 64) {
+				int o = t / Q, q = t % Q;
+				u32 s = 0, mh = 0x7F007F00u, ml = 0x7F007F00u;
+				for (int j = 0; j < per; ++j) {
+					u32 x = soft_ld(lvl, 8 * o + j, q);
+					s |= (x & SIGN_BITS) >> j;
+					mh = pk_min(mh, abs_half(split_hi(x)));
+					ml = pk_min(ml, abs_half(split_lo(x)));
+				}
+				ts[t] = s;
+				mins[2 * t] = mh;
+				mins[2 * t + 1] = ml;
+			}
+		}
+		wave_sync();
+		// per quad: weakest magnitude and parity over the whole node
+		PFOR_LANES(lane) {
+			if (lane < Q) {
+				u32 mh = 0x7F007F00u, ml = 0x7F007F00u, px = 0;
+				for (int o = 0; o < noct; ++o) {
+					int t = o * Q + lane;
+					mh = pk_min(mh, mins[2 * t]);
+					ml = pk_min(ml, mins[2 * t + 1]);
+					px ^= ts[t];
+				}
+				px ^= (px >> 4) & 0x0F0F0F0Fu;
+				px ^= (px >> 2) & 0x03030303u;
+				px ^= (px >> 1) & 0x01010101u;
+				wk[3 * lane] = mh;
+				wk[3 * lane + 1] = ml;
+				wk[3 * lane + 2] = (px & 0x01010101u) * 0xFFu; // all 8 element bits of the odd-parity frames
+			}
+		}
+		wave_sync();
+		// every position tied for the minimum is multiplied by the parity (polar_helper.hh:169-172)
+		PFOR_LANES(lane) {
+			for (int t = lane; t < n; t += 64) {
+				int o = t / Q, q = t % Q;
+				u32 wh = wk[3 * q], wl = wk[3 * q + 1], odd = wk[3 * q + 2];
+				u32 s = ts[t];
+				if (odd) {
+					u32 tie = 0;
+					for (int j = 0; j < per; ++j) {
+						u32 x = soft_ld(lvl, 8 * o + j, q);
+						u32 eq = eq_half(abs_half(split_hi(x)), wh) | (eq_half(abs_half(split_lo(x)), wl) >> 8);
+						tie |= eq >> j;
+					}
+					s ^= tie & odd;
+				}
+				put_bits(p, pidx(p.eb, 0) + t, j0, len, s, 0);
+				ts[t] = s;
+				tz[t] = 0;
+			}
+		}
+		wave_sync();
+		trans_emit(ts, tz, len, 1, row);
+	}
+
+	// rate1_comb (polar_decoder.hh:76-84): node of level lvl at hrd, left child decided
+	PDEV void rate1_comb(int lvl, u32 hrd, u32 row)
+	{
+		int h = 1 << (lvl - 1);
+		Planes c = planes(lvl - 1, hrd), o = planes(lvl, hrd);
+		int noct = h >= 8 ? h >> 3 : 1, per = h >= 8 ? 8 : h;
+		int n = noct * Q;
+		u32 *ts = node_tmp(lvl - 1, h), *tz = ts + n; // the left child's LLR region is dead by now
+		int j0 = (int)(o.eb & 7); // nonzero only when the whole node fits one octet
+		PFOR_LANES(lane) {
+			for (int t = lane; t < n; t += 64) {
+				int oc = t / Q, q = t % Q;
+				int il = pidx(c.eb, 0) + t;
+				u32 ls = c.s[il], lz = c.z[il];
+				u32 rs = 0, rz = 0;
+				for (int j = 0; j < per; ++j) {
+					int i = 8 * oc + j;
+					int sh = h >= 8 ? j : j0 + j;
+					u32 r = madd4(ls << sh, lz << sh, soft_ld(lvl, i, q), soft_ld(lvl, i + h, q));
+					rs |= (r & SIGN_BITS) >> j;
+					rz |= zero_bytes(r) >> j;
+				}
+				ts[t] = rs;
+				tz[t] = rz;
+				if (h >= 8) {
+					o.s[pidx(o.eb, 0) + t] = ls ^ rs;
+					o.z[pidx(o.eb, 0) + t] = lz | rz;
+					o.s[pidx(o.eb + h, 0) + t] = rs;
+					o.z[pidx(o.eb + h, 0) + t] = rz;
+				} else {
+					u32 lm = span_mask(j0, h), rm = span_mask(j0 + h, h);
+					u32 s = ls ^ ((rs >> j0) & lm), z = lz | ((rz >> j0) & lm);
+					s = bfi(rm, rs >> (j0 + h), s);
+					z = bfi(rm, rz >> (j0 + h), z);
+					o.s[il] = s;
+					o.z[il] = z;
+				}
+			}
+		}
+		wave_sync();
+		trans_emit(ts, tz, h, 0, row);
+	}
+
+	// the interpreter (polar_decoder.hh:131-464)
+	template <class P>
+	PDEV void run(const P *prog)
+	{
+		for (int pc = 0;; ++pc) {
+			u32 w = prog[pc].op_level, hrd = prog[pc].hrd, row = prog[pc].row;
+			u32 op = w & 255;
+			int lvl = (int)(w >> 8);
+			if (op == OP_END)
+				break;
+			switch (op) {
+			case OP_LEFT: soft_pass<0>(lvl, hrd); break;
+			case OP_RIGHT: soft_pass<1>(lvl, hrd); break;
+			case OP_RATE0_RIGHT: soft_pass<2>(lvl, hrd); break;
+			case OP_COMB: comb<false>(lvl, hrd); break;
+			case OP_RATE0_COMB: comb<true>(lvl, hrd); break;
+			case OP_RATE0: rate0(lvl, hrd); break;
+			case OP_RATE1: rate1(lvl, hrd, row); break;
+			case OP_REP: rep(lvl, hrd, row); break;
+			case OP_SPC: spc(lvl, hrd, row); break;
+			case OP_RATE1_COMB: rate1_comb(lvl, hrd, row); break;
+			default: break;
+			}
+		}
+	}
+};
+
+} // namespace polar

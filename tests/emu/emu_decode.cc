@@ -1,0 +1,109 @@
+// tests/emu/emu_decode.cc -- TEST INFRASTRUCTURE ONLY.
+//
+// Compiles polar_amd/csrc/sc_core.hpp for the host: the 64 lanes of a wavefront run one after
+// another inside every PFOR_LANES region, and the handful of gfx950 instructions the core
+// relies on (v_pk_add_i16 clamp, v_pk_sub_i16 clamp, v_pk_min/max_i16, v_perm_b32) are
+// emulated from their ISA definitions. This lets the CPU test-suite check the decoder's bit
+// tricks and addressing against the oracle without a GPU. It is never part of the product.
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define POLAR_EMU 1
+#define PDEV inline
+#define PFOR_LANES(lane) for (int lane = 0; lane < 64; ++lane)
+
+namespace polar {
+typedef uint32_t u32;
+struct alignas(16) u32x4 { u32 x, y, z, w; };
+static inline int16_t sat16(int v) { return (int16_t)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+#define EMU_PK(name, expr) \
+	static inline u32 name(u32 a, u32 b) \
+	{ \
+		u32 r = 0; \
+		for (int h = 0; h < 2; ++h) { \
+			int x = (int16_t)(a >> (16 * h)), y = (int16_t)(b >> (16 * h)); \
+			r |= (u32)(uint16_t)(expr) << (16 * h); \
+		} \
+		return r; \
+	}
+EMU_PK(pk_add_sat, sat16(x + y))
+EMU_PK(pk_sub_sat, sat16(x - y))
+EMU_PK(pk_min, (int16_t)(x < y ? x : y))
+EMU_PK(pk_max, (int16_t)(x > y ? x : y))
+// V_PERM_B32: byte select from {S0,S1} (S0 = bytes 4..7), 8..11 replicate a sign bit, 12 = 0x00, >=13 = 0xFF
+static inline u32 perm(u32 s0, u32 s1, u32 sel)
+{
+	uint64_t in = ((uint64_t)s0 << 32) | s1;
+	u32 r = 0;
+	for (int k = 0; k < 4; ++k) {
+		u32 s = (sel >> (8 * k)) & 0xFF, b;
+		if (s >= 13) b = 0xFF;
+		else if (s == 12) b = 0;
+		else if (s >= 8) b = ((in >> (16 * (s - 8) + 15)) & 1) ? 0xFF : 0;
+		else b = (u32)(in >> (8 * s)) & 0xFF;
+		r |= b << (8 * k);
+	}
+	return r;
+}
+static inline void wave_sync() {}
+}
+
+#include "../../polar_amd/csrc/sc_core.hpp"
+#include "../../polar_amd/csrc/program.hpp"
+
+using namespace polar;
+
+template <int Q, int RL>
+static int run(int8_t *msg, const int8_t *cw, const HostProgram &hp, size_t frames)
+{
+	typedef Group<Q, RL> G;
+	const int FR = 4 * Q;
+	std::vector<u32> lds(G::LDS_DWORDS), soft((size_t)Q << hp.top), planes(((size_t)Q << hp.top) / 8 * 2 + 2);
+	for (size_t g0 = 0; g0 < frames; g0 += FR) {
+		// poison everything a fresh wave would find uninitialised
+		for (auto &v : lds) v = 0xDEADBEEF;
+		for (auto &v : soft) v = 0xDEADBEEF;
+		for (auto &v : planes) v = 0xDEADBEEF;
+		G g;
+		g.sl = lds.data();
+		g.hls = g.sl + G::LDS_SOFT;
+		g.hlz = g.hls + G::LDS_PLANE;
+		g.tl = g.hlz + G::LDS_PLANE;
+		g.sg = soft.data();
+		g.hgs = planes.data();
+		g.hgz = planes.data() + planes.size() / 2;
+		g.top = hp.top;
+		int valid = (int)(frames - g0 < (size_t)FR ? frames - g0 : FR);
+		bool fast = valid == FR && frames % 4 == 0;
+		g.in = InVec<Q>{(const uint8_t *)cw + g0, frames, valid, fast};
+		g.out = OutRows<Q>{(uint8_t *)msg + g0, frames, valid, fast};
+		g.run(hp.ops.data());
+	}
+	return 0;
+}
+
+extern "C" int emu_decode(int8_t *msg, const int8_t *cw, const uint8_t *prog, int len, size_t frames, int Q, int RL)
+{
+	HostProgram hp;
+	int err = translate_program(prog, len, hp);
+	if (err)
+		return -err;
+#define CASE(q, r) if (Q == q && RL == r) return run<q, r>(msg, cw, hp, frames) ? -100 : (int)hp.rows;
+	CASE(1, 4) CASE(1, 6) CASE(2, 5) CASE(4, 4) CASE(4, 7) CASE(4, 9) CASE(8, 6) CASE(16, 7) CASE(16, 5)
+#undef CASE
+	return -101;
+}
+
+extern "C" unsigned emu_op(int which, unsigned a, unsigned b, unsigned hs, unsigned hz)
+{
+	switch (which) {
+	case 0: return prod4(a, b);
+	case 1: return qadd4(a, b);
+	case 2: return madd4(hs, hz, a, b);
+	case 3: return zero_bytes(a);
+	case 4: return symbols(a, b);
+	}
+	return 0;
+}

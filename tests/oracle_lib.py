@@ -70,7 +70,7 @@ class Oracle:
 
     def compile(self, frozen, level):
         frozen = _c(frozen, np.uint8)
-        prog = np.zeros((1 << level) + 2, np.uint8)
+        prog = np.zeros(2 * (1 << level) + 2, np.uint8)  # worst case 2N+1 bytes
         n = self.L.oracle_compile(_ptr(prog), _ptr(frozen), level)
         if n < 0:
             raise ValueError("frozen set not compilable (reference would assert)")
@@ -150,7 +150,7 @@ class Ref:
 
     def compile(self, frozen, level):
         frozen = _c(frozen, np.uint8)
-        prog = np.zeros((1 << level) + 2, np.uint8)
+        prog = np.zeros(2 * (1 << level) + 2, np.uint8)  # worst case 2N+1 bytes
         n = self.L.ref_compile(_ptr(prog), _ptr(frozen), level)
         return prog[:n].copy()
 

@@ -1,0 +1,196 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/polar_hip.h), against the
+oracle on the same inputs and against the committed golden vectors from the reference.
+Bit-exact: everything here is int8 / byte work."""
+import numpy as np
+import pytest
+import torch
+
+from inputs import corner_frames, family_llr, pm1_message, rand_bytes
+from oracle_lib import fnv1a64
+
+pytestmark = pytest.mark.gpu
+
+
+def _code(oracle, M, code="const0", K=None):
+    N = 1 << M
+    if code == "const0":
+        fro, _ = oracle.const0(M, K or N // 2)
+        return fro
+    return oracle.freezer(M, 0.5, 0.5)[0]
+
+
+def _decode(session, llr, prog, rows):
+    import polar_amd
+
+    out = np.zeros((max(rows, 1), llr.shape[1]), np.int8)
+    polar_amd.PolarDecoder(session)(out, np.ascontiguousarray(llr), prog)
+    return out[:rows]
+
+
+def test_native_library_loaded(session):
+    import polar_amd
+
+    maps = open("/proc/self/maps").read()
+    assert polar_amd.LIB_PATH in maps
+
+
+def test_decoder_golden_kats(session, oracle, golden):
+    meta, arr = golden
+    for k in meta["decoder_kats"]:
+        M = k["M"]
+        N = 1 << M
+        fro = _code(oracle, M, k["code"])
+        K = int((fro == 0).sum())
+        prog = oracle.compile(fro, M)
+        cw = oracle.encode(pm1_message(k["msg_seed"], K, 8), fro, M, 0)
+        llr = corner_frames(N) if k["family"] == "corner" else family_llr(k["family"], k["llr_seed"], cw)
+        out = _decode(session, llr, prog, K)
+        assert (out == arr[k["name"] + "_out"]).all(), k["name"]
+
+
+@pytest.mark.parametrize("M", [12, 14, 16])
+def test_decoder_golden_digests(session, oracle, golden, M):
+    meta, _ = golden
+    N = 1 << M
+    fro = _code(oracle, M)
+    prog = oracle.compile(fro, M)
+    for k in [k for k in meta["decoder_digests"] if k["M"] == M]:
+        cw = oracle.encode(pm1_message(k["msg_seed"], N // 2, k["frames"]), fro, M, 1)
+        llr = family_llr(k["family"], k["llr_seed"], cw)
+        out = _decode(session, llr, prog, N // 2)
+        assert "%016x" % fnv1a64(out) == k["out_fnv"], (M, k["family"])
+
+
+@pytest.mark.parametrize("fpw,rl", [(4, 11), (8, 10), (16, 9), (32, 8), (64, 7), (16, 10), (16, 8), (64, 6)])
+def test_decoder_vs_oracle_all_variants(session, oracle, fpw, rl):
+    """Every built kernel variant, ragged frame counts (tail groups, unaligned rows)."""
+    session.configure(fpw, rl, 0)
+    try:
+        for M, frames in ((1, 5), (2, 64), (3, 7), (5, 130), (8, 257), (10, 96), (11, 33), (13, 40)):
+            N = 1 << M
+            for code in ("const0", "freezer"):
+                fro = _code(oracle, M, code)
+                K = int((fro == 0).sum())
+                if K in (0, N) and M > 2:
+                    continue
+                prog = oracle.compile(fro, M)
+                cw = oracle.encode(pm1_message(M, max(K, 1), frames)[:K], fro, M, 0)
+                for fam in ("awgn-1", "uniform", "small"):
+                    llr = family_llr(fam, M + frames, cw)
+                    assert (_decode(session, llr, prog, K) == oracle.decode(llr, prog)).all(), (M, frames, code, fam)
+    finally:
+        session.configure(0, 0, 0)
+
+
+def test_decoder_every_opcode(session, oracle):
+    rng = np.random.default_rng(11)
+    seen = set()
+    for M in range(1, 10):
+        N = 1 << M
+        for trial in range(12):
+            b = 1 << int(rng.integers(0, M + 1))
+            fr = np.repeat((rng.random(N // b) < rng.random()).astype(np.uint8), b)
+            for i in range(0, N, 2):
+                if fr[i] == 0 and fr[i + 1] == 1:
+                    fr[i], fr[i + 1] = 1, 0
+            prog = oracle.compile(fr, M)
+            seen.update(prog[1:-1].tolist())
+            K = int((fr == 0).sum())
+            llr = rand_bytes(M * 100 + trial, (N, 36)).view(np.int8)
+            assert (_decode(session, llr, prog, K) == oracle.decode(llr, prog)).all(), (M, trial)
+    assert seen == set(range(10))
+
+
+def test_empty_and_device_buffers(session, oracle):
+    import polar_amd
+
+    M = 10
+    N = 1 << M
+    fro = _code(oracle, M)
+    prog = oracle.compile(fro, M)
+    dec = polar_amd.PolarDecoder(session)
+    dec(np.zeros((N // 2, 0), np.int8), np.zeros((N, 0), np.int8), prog)  # empty batch is a no-op
+    cw = oracle.encode(pm1_message(1, N // 2, 512), fro, M, 0)
+    llr = family_llr("awgn-1", 3, cw)
+    d_llr = torch.from_numpy(llr).cuda()
+    d_msg = torch.zeros((N // 2, 512), dtype=torch.int8, device="cuda")
+    dec(d_msg, d_llr, prog)
+    assert (d_msg.cpu().numpy() == oracle.decode(llr, prog)).all()
+    assert (d_llr.cpu().numpy() == llr).all()  # the codeword is not modified (polar_decoder.hh:136-137)
+    with pytest.raises(polar_amd.PolarError):
+        dec(d_msg, d_llr, np.array([10, 0, 255], np.uint8))
+
+
+def test_encoders(session, oracle, golden):
+    import polar_amd
+
+    meta, arr = golden
+    for k in meta["encoder_kats"]:
+        M = k["M"]
+        N = 1 << M
+        fro = _code(oracle, M)
+        msg = pm1_message(k["msg_seed"], N // 2, k["frames"])
+        cw = np.zeros((N, k["frames"]), np.int8)
+        enc = (polar_amd.PolarSysEnc if k["systematic"] else polar_amd.PolarEncoder)(M, session)
+        enc(cw, msg, fro)
+        assert "%016x" % fnv1a64(cw) == k["cw_fnv"], k
+    fro = _code(oracle, 8)
+    out = np.zeros((256, arr["enc_ternary_in"].shape[1]), np.int8)
+    polar_amd.PolarEncoder(8, session)(out, np.ascontiguousarray(arr["enc_ternary_in"]), fro)
+    assert (out == arr["enc_ternary_out"]).all()
+    # wide (multiple-of-4 frames) path and other rates against the oracle
+    for M, K, frames in ((6, 20, 64), (11, 700, 128), (14, 8192, 32)):
+        fro = _code(oracle, M, K=K)
+        msg = pm1_message(M, K, frames)
+        for sysf in (0, 1):
+            cw = np.zeros((1 << M, frames), np.int8)
+            (polar_amd.PolarSysEnc if sysf else polar_amd.PolarEncoder)(M, session)(cw, msg, fro)
+            assert (cw == oracle.encode(msg, fro, M, sysf)).all(), (M, sysf)
+
+
+def test_systematic_chain(session, oracle):
+    """testbench.cc:129-183 on the device: sysenc -> (noise) -> decode -> re-encode -> gather."""
+    import polar_amd
+
+    for M, frames in ((10, 100), (12, 64)):
+        N = 1 << M
+        fro = _code(oracle, M)
+        prog = oracle.compile(fro, M)
+        msg = pm1_message(9, N // 2, frames)
+        cw = np.zeros((N, frames), np.int8)
+        polar_amd.PolarSysEnc(M, session)(cw, msg, fro)
+        assert (cw[fro == 0] == msg).all()  # testbench.cc:143-146
+        for fam in ("awgn+1", "uniform"):
+            llr = family_llr(fam, 21, cw)
+            dec = _decode(session, llr, prog, N // 2).copy()
+            polar_amd.PolarEncoder(M, session).extract_systematic(dec, fro)
+            exp = oracle.systematic_extract(oracle.decode(llr, prog), fro, M)
+            assert (dec == exp).all(), (M, fam)
+            if fam == "awgn+1":
+                assert (dec == msg).all()
+
+
+def test_full_size_properties(session, oracle):
+    """N = 2^16 at batch sizes the oracle cannot follow: noise-free and mildly noisy systematic
+    codewords must decode to the transmitted message; a checksum over a subset is compared
+    with the oracle."""
+    import polar_amd
+
+    M, frames = 16, 2048
+    N = 1 << M
+    fro = _code(oracle, M)
+    prog = oracle.compile(fro, M)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    msg = (1 - 2 * torch.randint(0, 2, (N // 2, frames), generator=g, device="cuda", dtype=torch.int8)).contiguous()
+    cw = torch.zeros((N, frames), dtype=torch.int8, device="cuda")
+    polar_amd.PolarSysEnc(M, session)(cw, msg, fro)
+    assert bool((cw[torch.from_numpy(fro == 0).cuda()] == msg).all())
+    sigma = float(np.sqrt(1.0 / (2.0 * 10.0 ** (0.0 / 10.0))))  # Es/N0 = 0 dB: far above the waterfall
+    noisy = cw.to(torch.float32) + sigma * torch.randn(cw.shape, generator=g, device="cuda")
+    llr = torch.clamp(torch.round(noisy * (2.0 / sigma**2)), -128, 127).to(torch.int8).contiguous()
+    out = torch.zeros((N // 2, frames), dtype=torch.int8, device="cuda")
+    polar_amd.PolarDecoder(session)(out, llr, prog)
+    sub = llr[:, :48].cpu().numpy().copy()
+    assert (out[:, :48].cpu().numpy() == oracle.decode(sub, prog)).all()
+    polar_amd.PolarEncoder(M, session).extract_systematic(out, fro)
+    assert bool((out == msg).all())

@@ -1,0 +1,171 @@
+"""CPU-only checks of the product's host side: code construction and compiler of
+libpolar_hip.so against the golden vectors, the C ABI's symbol table and error behaviour, and
+the wavefront decoder core (polar_amd/csrc/sc_core.hpp) run through the host emulation build
+(tests/emu) against the oracle. No compute entry point is called: there is no GPU here."""
+import ctypes
+import re
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from inputs import corner_frames, family_llr, pm1_message
+from oracle_lib import fnv1a64
+
+
+def test_library_exports_every_declared_symbol():
+    import polar_amd
+    from polar_amd._lib import SYMBOLS
+
+    header = open(os.path.join(ROOT, "include", "polar_hip.h")).read()
+    declared = set(re.findall(r"\b(polar_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(SYMBOLS), declared ^ set(SYMBOLS)
+    L = ctypes.CDLL(polar_amd.LIB_PATH)
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_construction_matches_golden(golden):
+    import polar_amd
+
+    meta, arr = golden
+    p = polar_amd.testbench_probability()
+    for M_s, e in meta["codes"].items():
+        M = int(M_s)
+        N = 1 << M
+        fro = np.zeros(N, np.uint8)
+        polar_amd.PolarCodeConst0()(fro, M, N // 2, p)
+        assert "%016x" % fnv1a64(fro) == e["const0_frozen_fnv"], M
+        prog = np.zeros(2 * N + 1, np.uint8)
+        if "const0_prog_len" in e:
+            n = polar_amd.PolarCompiler()(prog, fro, M)
+            assert n == e["const0_prog_len"] and "%016x" % fnv1a64(prog[:n]) == e["const0_prog_fnv"], M
+            assert polar_amd.lib.polar_program_rows(prog.ctypes.data, n) == N // 2
+        for tag, th in (("half", 0.5), ("eps", float(np.finfo(np.float32).eps))):
+            fz = np.zeros(N, np.uint8)
+            K = polar_amd.PolarFreezer()(fz, M, 0.5, th)
+            assert K == e["freezer_%s_K" % tag] and "%016x" % fnv1a64(fz) == e["freezer_%s_frozen_fnv" % tag]
+            if "freezer_%s_prog_len" % tag in e:
+                n = polar_amd.PolarCompiler()(prog, fz, M)
+                assert n == e["freezer_%s_prog_len" % tag] and "%016x" % fnv1a64(prog[:n]) == e["freezer_%s_prog_fnv" % tag]
+    prog = np.zeros(16, np.uint8)
+    n = polar_amd.PolarCompiler()(prog, np.array([1, 1, 1, 0, 1, 0, 0, 0], np.uint8), 3)
+    assert prog[:n].tolist() == [3, 0, 5, 1, 6, 2, 255]
+
+
+def test_error_behaviour():
+    import polar_amd
+
+    # [info, frozen]: the reference asserts level > 0 (polar_compiler.hh:23); here an error code
+    with pytest.raises(polar_amd.PolarError) as e:
+        polar_amd.PolarCompiler()(np.zeros(8, np.uint8), np.array([0, 1], np.uint8), 1)
+    assert e.value.code == -2
+    bad = [
+        [3, 0, 5, 1, 6, 2],         # no terminator
+        [3, 0, 5, 1, 6, 255],       # ends below the top level (polar_decoder.hh:463)
+        [3, 2, 255],                # comb with nothing to combine
+        [3, 7, 255],                # unbalanced rate0_right
+        [1, 0, 5, 255],             # left<1> (polar_decoder.hh:170)
+        [0, 4, 255], [40, 4, 255],  # level out of range (polar_decoder.hh:135)
+        [3, 11, 255],               # unknown opcode (polar_decoder.hh:460)
+    ]
+    for p in bad:
+        p = np.array(p, np.uint8)
+        assert polar_amd.lib.polar_program_rows(p.ctypes.data, p.size) == -2, p
+    assert b"malformed" in polar_amd.lib.polar_hip_last_error()
+    # no device in the CPU container: creation must fail loudly, not fall back
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(polar_amd.PolarError) as e:
+            polar_amd.Session(0)
+        assert e.value.code == -5
+
+
+def _unpack(u):
+    return np.array([u], np.uint32).view(np.int8).tolist()
+
+
+def _pack(v):
+    return int(np.array(v, np.int8).view(np.uint32)[0])
+
+
+def test_packed_arithmetic_exhaustive(emu, oracle):
+    """prod4 / qadd4 / madd4 (v_pk_*_i16 + v_perm_b32 formulation) against the oracle for every
+    int8 pair, all three partial-sum values, with garbage in the ignored mask bits."""
+    L = oracle.L
+    for a in range(-128, 128):
+        for b0 in range(-128, 128, 4):
+            bs = [b0, b0 + 1, b0 + 2, b0 + 3]
+            A, B = _pack([a] * 4), _pack(bs)
+            assert _unpack(emu.emu_op(0, A, B, 0, 0)) == [L.oracle_prod(a, b) for b in bs]
+            assert _unpack(emu.emu_op(0, B, A, 0, 0)) == [L.oracle_prod(b, a) for b in bs]
+            assert _unpack(emu.emu_op(1, A, B, 0, 0)) == [L.oracle_qadd(a, b) for b in bs]
+            for h in (-1, 0, 1):
+                hs = (0x80808080 if h < 0 else 0) | 0x35124C7A & 0x7F7F7F7F
+                hz = (0x80808080 if h == 0 else 0) | 0x1B2E5D33 & 0x7F7F7F7F
+                assert _unpack(emu.emu_op(2, A, B, hs, hz)) == [L.oracle_madd(h, a, b) for b in bs]
+                assert _unpack(emu.emu_op(2, B, A, hs, hz)) == [L.oracle_madd(h, b, a) for b in bs]
+    # mixed partial sums inside one dword
+    hs, hz = 0x80000080, 0x00800000  # frames: -1, +1, 0, -1
+    got = _unpack(emu.emu_op(2, _pack([-128, 100, 7, -128]), _pack([3, 100, -128, -128]), hs, hz))
+    assert got == [L.oracle_madd(-1, -128, 3), L.oracle_madd(1, 100, 100), L.oracle_madd(0, 7, -128), L.oracle_madd(-1, -128, -128)]
+
+
+def _emu_decode(emu, llr, prog, Q, RL):
+    N, F = llr.shape
+    out = np.zeros((N, F), np.int8)
+    rows = emu.emu_decode(out.ctypes.data, llr.ctypes.data, prog.ctypes.data, prog.size, F, Q, RL)
+    assert rows >= 0, rows
+    return out[:rows]
+
+
+@pytest.mark.parametrize("Q,RL", [(1, 4), (2, 5), (4, 4), (4, 7), (8, 6), (16, 5)])
+def test_emulated_core_polar_codes(emu, oracle, Q, RL):
+    """All LDS / scratch / input placements of the level vectors: RL below, at and above the code size."""
+    for M in (1, 2, 3, 4, 5, 6, 8, 10):
+        N = 1 << M
+        fro, _ = oracle.const0(M, N // 2)
+        prog = oracle.compile(fro, M)
+        cw = oracle.encode(pm1_message(5, N // 2, 4 * Q * 2 + 3), fro, M, 0)
+        for fam in ("awgn-1", "uniform", "small"):
+            llr = family_llr(fam, 9, cw)
+            assert (_emu_decode(emu, llr, prog, Q, RL) == oracle.decode(llr, prog)).all(), (M, fam)
+        llr = np.ascontiguousarray(corner_frames(N))
+        assert (_emu_decode(emu, llr, prog, Q, RL) == oracle.decode(llr, prog)).all(), (M, "corner")
+
+
+def test_emulated_core_every_opcode(emu, oracle):
+    rng = np.random.default_rng(3)
+    seen = set()
+    for M in range(1, 9):
+        N = 1 << M
+        for trial in range(24):
+            b = 1 << int(rng.integers(0, M + 1))
+            fr = np.repeat((rng.random(N // b) < rng.random()).astype(np.uint8), b)
+            for i in range(0, N, 2):
+                if fr[i] == 0 and fr[i + 1] == 1:
+                    fr[i], fr[i + 1] = 1, 0
+            prog = oracle.compile(fr, M)
+            seen.update(prog[1:-1].tolist())
+            for (Q, RL), fam in zip(((1, 4), (2, 5), (4, 4), (8, 6)), ("uniform", "small", "uniform", "awgn-1")):
+                F = 4 * Q + 1
+                cw = oracle.encode(pm1_message(trial, max(1, int((fr == 0).sum())), F)[: int((fr == 0).sum())], fr, M, 0)
+                llr = family_llr(fam, trial, cw)
+                assert (_emu_decode(emu, llr, prog, Q, RL) == oracle.decode(llr, prog)).all(), (M, trial, Q, RL)
+    assert seen == set(range(10))
+
+
+def test_emulated_core_golden_digest(emu, oracle, golden):
+    """The emulated device core reproduces the reference's own output digest at N = 4096."""
+    meta, _ = golden
+    M = 12
+    N = 1 << M
+    fro, _ = oracle.const0(M, N // 2)
+    prog = oracle.compile(fro, M)
+    for k in [k for k in meta["decoder_digests"] if k["M"] == M]:
+        cw = oracle.encode(pm1_message(k["msg_seed"], N // 2, k["frames"]), fro, M, 1)
+        llr = family_llr(k["family"], k["llr_seed"], cw)
+        assert "%016x" % fnv1a64(_emu_decode(emu, llr, prog, 4, 9)) == k["out_fnv"]
+        assert "%016x" % fnv1a64(_emu_decode(emu, llr, prog, 16, 7)) == k["out_fnv"]
