@@ -90,6 +90,15 @@ int polar_hip_encode(polar_hip_handle *h, int systematic, int8_t *codeword, cons
  * `decoded` (K x frames). */
 int polar_hip_systematic_extract(polar_hip_handle *h, int8_t *decoded, const uint8_t *frozen, int level, size_t frames, int where);
 
+/* Bench counters of testbench.cc:185-192 over flat symbol arrays:
+ *   counters[0] += #(noisy*orig < 0)  (awgn_errors)      counters[1] += #(noisy == 0)  (quantization_erasures)
+ *   counters[2] += #(decoded*message <= 0)  (uncorrected_errors, 0 counts as an error)
+ *   counters[3] += #(decoded == 0)  (ambiguity_erasures)
+ * With where = POLAR_DEVICE `counters` is a device pointer too (int64[4], added to atomically),
+ * ready for the RCCL all-reduce across frame shards. */
+int polar_hip_count(polar_hip_handle *h, int64_t *counters, const int8_t *noisy, const int8_t *orig, size_t n_code,
+	const int8_t *decoded, const int8_t *message, size_t n_mesg, int where);
+
 /* Blocks until all work enqueued through this handle has finished. */
 int polar_hip_synchronize(polar_hip_handle *h);
 

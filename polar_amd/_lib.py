@@ -24,6 +24,7 @@ SYMBOLS = {
     "polar_hip_decode_async": ([_vp, _i, _vp, _vp, _sz, _vp], _i),
     "polar_hip_encode": ([_vp, _i, _vp, _vp, _vp, _i, _sz, _i], _i),
     "polar_hip_systematic_extract": ([_vp, _vp, _vp, _i, _sz, _i], _i),
+    "polar_hip_count": ([_vp, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _i], _i),
     "polar_hip_synchronize": ([_vp], _i),
     "polar_hip_last_decode_ms": ([_vp], ctypes.c_float),
 }

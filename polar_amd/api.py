@@ -38,6 +38,12 @@ def _ptr(a):
     if hasattr(a, "data_ptr"):  # torch tensor
         if not a.is_contiguous():
             raise ValueError("buffers must be contiguous [elements][frames]")
+        if a.is_cuda:
+            # the library runs on its own stream: whatever torch still has queued on the
+            # tensor's producer stream must land first
+            import torch
+
+            torch.cuda.current_stream(a.device).synchronize()
         return ctypes.c_void_p(a.data_ptr()), DEVICE if a.is_cuda else HOST
     raise TypeError("expected a numpy array or a torch tensor")
 
@@ -121,6 +127,15 @@ class Session:
             rows = _check(lib.polar_program_rows(program.ctypes.data, program.size), "polar_program_rows")
             self._programs[key] = (pid, rows)
         return self._programs[key]
+
+    def count(self, counters, noisy, orig, decoded, message):
+        """testbench.cc:185-192: counters[4] (int64) += awgn_errors, quantization_erasures,
+        uncorrected_errors, ambiguity_erasures. Any of the two pairs may be None."""
+        ptrs = [_ptr(x) for x in (counters, noisy, orig, decoded, message)]
+        where = _where(*[w for _p, w in ptrs])
+        n_code = int(noisy.numel() if hasattr(noisy, "numel") else noisy.size) if noisy is not None else 0
+        n_mesg = int(decoded.numel() if hasattr(decoded, "numel") else decoded.size) if decoded is not None else 0
+        _check(lib.polar_hip_count(self._h, ptrs[0][0], ptrs[1][0], ptrs[2][0], n_code, ptrs[3][0], ptrs[4][0], n_mesg, where), "polar_hip_count")
 
     def synchronize(self):
         _check(lib.polar_hip_synchronize(self._h), "polar_hip_synchronize")

@@ -180,6 +180,57 @@ __global__ void __launch_bounds__(256) gather_rows_kernel(T *dst, const T *src, 
 		dst[r * cols + col] = src[(size_t)rows[r] * cols + col];
 }
 
+
+// Bench counters (testbench.cc:185-192) over flat symbol arrays, 16 symbols per load:
+//   c[0] += #(noisy * orig < 0)   c[1] += #(noisy == 0)   over n_code symbols
+//   c[2] += #(decoded * message <= 0)   c[3] += #(decoded == 0)   over n_mesg symbols
+__device__ __forceinline__ void count_pair(u32 a, u32 b, unsigned &lt, unsigned &za_n, unsigned &le)
+{
+	u32 za = zero_bytes(a), zb = zero_bytes(b), d = (a ^ b) & SIGN_BITS;
+	lt += __builtin_popcount(d & ~za & ~zb);
+	za_n += __builtin_popcount(za);
+	le += __builtin_popcount(d | za | zb);
+}
+
+__global__ void __launch_bounds__(256) count_kernel(unsigned long long *c, const uint8_t *noisy, const uint8_t *orig, size_t n_code, const uint8_t *decoded, const uint8_t *message, size_t n_mesg)
+{
+	unsigned v[4] = {0, 0, 0, 0}, unused = 0;
+	const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+	for (int part = 0; part < 2; ++part) {
+		const uint8_t *a = part ? decoded : noisy, *b = part ? message : orig;
+		size_t n = part ? n_mesg : n_code;
+		if (!n)
+			continue;
+		bool wide = ((uintptr_t)a % 16 == 0) && ((uintptr_t)b % 16 == 0);
+		size_t nvec = wide ? n / 16 : 0;
+		for (size_t i = tid; i < nvec; i += nt) {
+			u32x4 x = reinterpret_cast<const u32x4 *>(a)[i], y = reinterpret_cast<const u32x4 *>(b)[i];
+			unsigned &lt = part ? unused : v[0], &z = part ? v[3] : v[1], &le = part ? v[2] : unused;
+			count_pair(x.x, y.x, lt, z, le);
+			count_pair(x.y, y.y, lt, z, le);
+			count_pair(x.z, y.z, lt, z, le);
+			count_pair(x.w, y.w, lt, z, le);
+		}
+		for (size_t i = nvec * 16 + tid; i < n; i += nt) {
+			int x = (int8_t)a[i], y = (int8_t)b[i];
+			if (part) {
+				v[2] += x * y <= 0;
+				v[3] += x == 0;
+			} else {
+				v[0] += x * y < 0;
+				v[1] += x == 0;
+			}
+		}
+	}
+	for (int k = 0; k < 4; ++k) {
+		unsigned long long w = v[k];
+		for (int off = 32; off; off >>= 1)
+			w += __shfl_down(w, off, 64);
+		if ((threadIdx.x & 63) == 0 && w)
+			atomicAdd(&c[k], w);
+	}
+}
+
 // ---------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------
@@ -220,7 +271,7 @@ struct polar_hip_handle {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool timed = false;
 	std::vector<LoadedProgram> programs;
-	DeviceBuffer scratch, stage_in, stage_out, enc_tmp, tables;
+	DeviceBuffer scratch, stage_in, stage_out, enc_tmp, tables, counters;
 	std::vector<uint8_t> frozen_cache; // frozen set the device tables were built from
 	int cfg_frames_per_wave = 0, cfg_lds_level = 0, cfg_max_waves = 0;
 };
@@ -316,6 +367,7 @@ extern "C" void polar_hip_destroy(polar_hip_handle *h)
 	h->stage_out.release();
 	h->enc_tmp.release();
 	h->tables.release();
+	h->counters.release();
 	(void)hipEventDestroy(h->ev0);
 	(void)hipEventDestroy(h->ev1);
 	(void)hipStreamDestroy(h->stream);
@@ -634,6 +686,49 @@ extern "C" int polar_hip_systematic_extract(polar_hip_handle *h, int8_t *decoded
 	HIP_TRY(hipGetLastError());
 	if (where == POLAR_HOST)
 		HIP_TRY(hipMemcpyAsync(decoded, dev, (size_t)K * frames, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return POLAR_OK;
+}
+
+// ---- bench counters ----
+
+extern "C" int polar_hip_count(polar_hip_handle *h, int64_t *counters, const int8_t *noisy, const int8_t *orig, size_t n_code, const int8_t *decoded, const int8_t *message, size_t n_mesg, int where)
+{
+	if (!h || !counters || (where != POLAR_HOST && where != POLAR_DEVICE) || (n_code && (!noisy || !orig)) || (n_mesg && (!decoded || !message)))
+		return fail(POLAR_E_ARG, "polar_hip_count: bad argument");
+	int rc = use_device(h);
+	if (rc)
+		return rc;
+	const uint8_t *p[4] = {(const uint8_t *)noisy, (const uint8_t *)orig, (const uint8_t *)decoded, (const uint8_t *)message};
+	unsigned long long *c = (unsigned long long *)counters;
+	if (where == POLAR_HOST) {
+		// four staged arrays share stage_in; counters are accumulated on the device then added
+		size_t off[5] = {0, n_code, 2 * n_code, 2 * n_code + n_mesg, 2 * (n_code + n_mesg)};
+		for (int k = 0; k < 5; ++k)
+			off[k] = (off[k] + 15) / 16 * 16 + 16 * k;
+		if ((rc = h->stage_in.reserve(off[4] + 16)) || (rc = h->counters.reserve(32)))
+			return rc;
+		for (int k = 0; k < 4; ++k) {
+			size_t n = k < 2 ? n_code : n_mesg;
+			if (n)
+				HIP_TRY(hipMemcpyAsync((uint8_t *)h->stage_in.p + off[k], p[k], n, hipMemcpyHostToDevice, h->stream));
+			p[k] = (const uint8_t *)h->stage_in.p + off[k];
+		}
+		c = (unsigned long long *)h->counters.p;
+		HIP_TRY(hipMemsetAsync(c, 0, 32, h->stream));
+	}
+	size_t work = (n_code > n_mesg ? n_code : n_mesg) / 16 / 256 + 1;
+	unsigned blocks = (unsigned)(work < (size_t)h->cus * 8 ? work : (size_t)h->cus * 8);
+	hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(256), 0, h->stream, c, p[0], p[1], n_code, p[2], p[3], n_mesg);
+	HIP_TRY(hipGetLastError());
+	if (where == POLAR_HOST) {
+		int64_t tmp[4];
+		HIP_TRY(hipMemcpyAsync(tmp, c, 32, hipMemcpyDeviceToHost, h->stream));
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		for (int k = 0; k < 4; ++k)
+			counters[k] += tmp[k];
+		return POLAR_OK;
+	}
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	return POLAR_OK;
 }

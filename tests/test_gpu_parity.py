@@ -194,3 +194,23 @@ def test_full_size_properties(session, oracle):
     assert (out[:, :48].cpu().numpy() == oracle.decode(sub, prog)).all()
     polar_amd.PolarEncoder(M, session).extract_systematic(out, fro)
     assert bool((out == msg).all())
+
+
+def test_counters(session, oracle):
+    """testbench.cc:185-192 on the device against the oracle's counters, host and device buffers."""
+    for n_code, n_mesg, seed in ((4096 * 7, 2048 * 7, 1), (1000 * 3 + 5, 500 * 3 + 1, 2), (16, 0, 3)):
+        noisy = (rand_bytes(seed, (n_code,)) % 9).astype(np.int8) - 4
+        orig = pm1_message(seed + 10, 1, n_code)[0]
+        decoded = ((rand_bytes(seed + 20, (max(n_mesg, 1),)) % 3).astype(np.int8) - 1)[:n_mesg]
+        message = pm1_message(seed + 30, 1, max(n_mesg, 1))[0][:n_mesg]
+        exp = oracle.count(noisy, orig, decoded, message)
+        c = np.array([5, 6, 7, 8], np.int64)
+        session.count(c, noisy, orig, decoded if n_mesg else None, message if n_mesg else None)
+        assert (c - [5, 6, 7, 8]).tolist() == exp.tolist()
+        d = torch.zeros(4, dtype=torch.int64, device="cuda")
+        tn, to = torch.from_numpy(noisy).cuda(), torch.from_numpy(orig.copy()).cuda()
+        if n_mesg:
+            session.count(d, tn, to, torch.from_numpy(decoded.copy()).cuda(), torch.from_numpy(message.copy()).cuda())
+        else:
+            session.count(d, tn, to, None, None)
+        assert d.cpu().tolist() == exp.tolist()
