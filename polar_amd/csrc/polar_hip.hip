@@ -65,8 +65,8 @@ __global__ void __launch_bounds__(64) sc_decode_kernel(DecodeArgs a)
 	u32 *arena = a.scratch ? a.scratch + (size_t)b * a.block_dwords : nullptr;
 	const size_t plane = ((size_t)Q << a.top) / 8;
 	G g;
-	g.sl = lds;
-	g.hls = lds + G::LDS_SOFT;
+	g.sl = (lds_u32 *)lds;
+	g.hls = g.sl + G::LDS_SOFT;
 	g.hlz = g.hls + G::LDS_PLANE;
 	g.tl = g.hlz + G::LDS_PLANE;
 	g.sg = arena;
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64) sc_decode_kernel(DecodeArgs a)
 		bool fast = a.aligned && valid == 4 * Q && a.frames % 4 == 0;
 		g.in = InVec<Q>{a.cw + g0, a.frames, valid, fast};
 		g.out = OutRows<Q>{a.msg + g0, a.frames, valid, fast};
-		g.run(a.prog);
+		g.run((prog_ptr)a.prog);
 	}
 }
 

@@ -18,7 +18,7 @@ namespace polar {
 struct HostProgram {
 	int top = 0;        // level of the code, N = 1 << top
 	uint32_t rows = 0;  // message symbols emitted per frame (K for a compiled frozen set)
-	std::vector<DevOp> ops; // terminated by OP_END
+	std::vector<DevOp> ops; // terminated by two OP_END words
 };
 
 enum { MAX_LEVEL = 24 };
@@ -102,6 +102,7 @@ inline int translate_program(const uint8_t *prog, int length, HostProgram &out)
 		return 10;
 	DevOp e = {OP_END, 0, 0, 0};
 	out.ops.push_back(e);
+	out.ops.push_back(e); // the interpreter fetches one word ahead
 	out.rows = row;
 	return 0;
 }

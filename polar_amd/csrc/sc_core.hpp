@@ -25,6 +25,9 @@
 // so `plane << j` puts element j's bits of the 4 frames on the byte sign bits, where
 // v_perm_b32's sign-replicating selectors turn them into 16-bit lane masks.
 //
+// Address spaces are explicit on the hot paths (ds_* for LDS, global_* for scratch, s_load for
+// the instruction stream); only the rare nodes above the LDS levels use flat pointers.
+//
 // This header is compiled for the device by polar_hip.hip. tests/emu/ compiles the same text
 // for the host with POLAR_EMU defined (lanes run one after another inside PFOR_LANES) so the
 // bit tricks can be unit-tested without a GPU; the product never uses that build.
@@ -44,7 +47,7 @@ enum : u32 {
 
 // Device instruction word: the reference byte-code with the interpreter's running state
 // (lvl / hrd / msg of polar_decoder.hh:133-134) resolved at load time by the host.
-struct DevOp {
+struct alignas(16) DevOp {
 	u32 op_level; // opcode | node level << 8
 	u32 hrd;      // absolute position of the node in the partial-sum array
 	u32 row;      // first message row the node emits
@@ -55,7 +58,10 @@ struct DevOp {
 #define PDEV __device__ __forceinline__
 #define PFOR_LANES(lane) for (int lane = (int)(threadIdx.x & 63), once_ = 1; once_; once_ = 0)
 typedef short v2s_ __attribute__((ext_vector_type(2)));
-struct alignas(16) u32x4 { u32 x, y, z, w; };
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u32 lds_u32;
+typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+typedef const __attribute__((address_space(4))) DevOp *prog_ptr; // constant memory: scalar loads
 PDEV u32 pk_add_sat(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_add_sat(__builtin_bit_cast(v2s_, a), __builtin_bit_cast(v2s_, b))); }
 PDEV u32 pk_sub_sat(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2s_, a), __builtin_bit_cast(v2s_, b))); }
 PDEV u32 pk_min(u32 a, u32 b) { return __builtin_bit_cast(u32, __builtin_elementwise_min(__builtin_bit_cast(v2s_, a), __builtin_bit_cast(v2s_, b))); }
@@ -128,15 +134,49 @@ PDEV u32 eq_half(u32 x, u32 y)
 	u32 t = (d & 0x7FFF7FFFu) + 0x7FFF7FFFu;
 	return ~(t | d) & 0x80008000u;
 }
+// byte sign bits of the positions whose magnitude equals the weakest one (wh / wl: scaled halves)
+PDEV u32 tie_bits(u32 x, u32 wh, u32 wl)
+{
+	return eq_half(abs_half(split_hi(x)), wh) | (eq_half(abs_half(split_lo(x)), wl) >> 8);
+}
+// byte-replicated mask of the `len` (< 8) elements starting at octet offset j0
+PDEV u32 span_mask(int j0, int len)
+{
+	u32 b = (0xFFu >> j0) & ~(0xFFu >> (j0 + len));
+	return b * 0x01010101u;
+}
+// stages h = 1, 2, 4 of the transform (trans, polar_decoder.hh:15-27) inside one octet of planes
+PDEV void trans_octet(u32 &s, u32 &z, int len)
+{
+	if (len > 1) { s ^= (s << 1) & 0xAAAAAAAAu; z |= (z << 1) & 0xAAAAAAAAu; }
+	if (len > 2) { s ^= (s << 2) & 0xCCCCCCCCu; z |= (z << 2) & 0xCCCCCCCCu; }
+	if (len > 4) { s ^= (s << 4) & 0xF0F0F0F0u; z |= (z << 4) & 0xF0F0F0F0u; }
+}
+// parity (bit 0 of every byte -> all eight bits) of the element bits of one octet dword
+PDEV u32 odd_mask(u32 px)
+{
+	px ^= (px >> 4) & 0x0F0F0F0Fu;
+	px ^= (px >> 2) & 0x03030303u;
+	px ^= (px >> 1) & 0x01010101u;
+	return (px & 0x01010101u) * 0xFFu;
+}
 
 // ---- memory views ----
 
-struct Vec { // linear dword array in LDS or HBM scratch
+struct GVec { // linear dword array in the HBM scratch arena
 	u32 *p;
 	PDEV u32 ld(int t) const { return p[t]; }
 	PDEV void st(int t, u32 v) const { p[t] = v; }
 	PDEV u32x4 ld4(int t) const { return *reinterpret_cast<const u32x4 *>(p + t); }
 	PDEV void st4(int t, u32x4 v) const { *reinterpret_cast<u32x4 *>(p + t) = v; }
+};
+
+struct LVec { // linear dword array in LDS
+	lds_u32 *p;
+	PDEV u32 ld(int t) const { return p[t]; }
+	PDEV void st(int t, u32 v) const { p[t] = v; }
+	PDEV u32x4 ld4(int t) const { return *reinterpret_cast<const lds_u32x4 *>(p + t); }
+	PDEV void st4(int t, u32x4 v) const { *reinterpret_cast<lds_u32x4 *>(p + t) = v; }
 };
 
 // the caller's codeword buffer: row i of the group starts at in + i*stride (bytes)
@@ -151,6 +191,10 @@ template <int Q> struct InVec {
 		const uint8_t *r = p + (size_t)i * stride + 4 * q;
 		if (fast)
 			return *reinterpret_cast<const u32 *>(r);
+		return ld_slow(r, q);
+	}
+	PDEV u32 ld_slow(const uint8_t *r, int q) const
+	{
 		u32 v = 0;
 		for (int k = 0; k < 4; ++k)
 			if (4 * q + k < valid)
@@ -181,6 +225,11 @@ template <int Q> struct OutRows { // the caller's message buffer, same row layou
 			if (4 * q + k < valid)
 				r[k] = (uint8_t)(v >> (8 * k));
 	}
+};
+
+template <class T> struct Planes { // partial-sum bit planes of one node
+	T *s, *z;
+	u32 eb; // position of the node's first element inside the planes
 };
 
 // d[t] = fn(t, a[t], a[t + n]) for t < n: the shape of left / right / rate0_right and of the
@@ -215,114 +264,87 @@ struct Group {
 	static const int W = 1 << (RL + 1); // elements of the LDS partial-sum window
 	static const int LDS_SOFT = Q << (RL + 1), LDS_PLANE = (W / 8) * Q, LDS_TMP = 8 * Q;
 	static const int LDS_DWORDS = LDS_SOFT + 2 * LDS_PLANE + LDS_TMP;
-	u32 *sl;        // LDS soft arena, LDS_SOFT dwords (level l at Q << l)
-	u32 *hls, *hlz; // LDS partial-sum planes (sign, zero), LDS_PLANE dwords each, index by position mod W
-	u32 *tl;        // LDS scratch for nodes smaller than one octet, LDS_TMP dwords
-	u32 *sg;        // scratch soft arena, Q << top dwords
-	u32 *hgs, *hgz; // scratch partial-sum planes, (Q << top) / 8 dwords each
+	lds_u32 *sl;        // LDS soft arena, LDS_SOFT dwords (level l at Q << l)
+	lds_u32 *hls, *hlz; // LDS partial-sum planes (sign, zero), LDS_PLANE dwords each, index by position mod W
+	lds_u32 *tl;        // LDS scratch, LDS_TMP dwords
+	u32 *sg;            // scratch soft arena, Q << top dwords
+	u32 *hgs, *hgz;     // scratch partial-sum planes, (Q << top) / 8 dwords each
 	InVec<Q> in;
 	OutRows<Q> out;
 	int top;
 
-	// plane index / shift of element e of a node whose first element sits at position eb
+	// plane dword of element e for frame quad q
 	static PDEV int pidx(u32 e, int q) { return (int)(e >> 3) * Q + q; }
 
+	PDEV Planes<lds_u32> lplanes(u32 hrd) const { return Planes<lds_u32>{hls, hlz, hrd & (u32)(W - 1)}; }
+	PDEV Planes<u32> gplanes(u32 hrd) const { return Planes<u32>{hgs, hgz, hrd}; }
+	// flat-pointer view of either, for the rare nodes above the LDS levels
+	PDEV Planes<u32> fplanes(int node_level, u32 hrd) const
+	{
+		if (node_level <= RL)
+			return Planes<u32>{(u32 *)hls, (u32 *)hlz, hrd & (u32)(W - 1)};
+		return gplanes(hrd);
+	}
+	PDEV u32 *fregion(int lvl) const // flat pointer to the level-lvl LLR region (lvl < top)
+	{
+		if (lvl > RL)
+			return sg + (Q << lvl);
+		return (u32 *)sl + (Q << lvl);
+	}
+
+	// LLR vector of a node above the LDS levels (or the input), runtime placement
+	struct AnySrc {
+		const Group *g;
+		const u32 *base; // null: the caller's input
+		PDEV u32 ld(int t) const { return base ? base[t] : g->in.ld(t); }
+	};
+	PDEV AnySrc any_src(int lvl) const { return AnySrc{this, lvl == top ? nullptr : fregion(lvl)}; }
+
 	// ---- f / g / qadd passes: polar_decoder.hh:28-51 ----
-	template <class A, class D>
-	PDEV void pass_left(const A &a, const D &d, int n)
+	template <int KIND, class A, class D, class H>
+	PDEV void pass(const A &a, const D &d, int n, const H *hs, const H *hz, u32 eb)
 	{
-		ew_pairs(a, d, n, [](int, u32 x, u32 y) { return prod4(x, y); });
+		if (KIND == 0)
+			ew_pairs(a, d, n, [](int, u32 x, u32 y) { return prod4(x, y); });
+		else if (KIND == 2)
+			ew_pairs(a, d, n, [](int, u32 x, u32 y) { return qadd4(x, y); });
+		else
+			ew_pairs(a, d, n, [=](int t, u32 x, u32 y) {
+				u32 e = eb + (u32)(t / Q);
+				int i = pidx(e, t % Q), sh = (int)(e & 7);
+				return madd4(hs[i] << sh, hz[i] << sh, x, y);
+			});
 	}
-	template <class A, class D>
-	PDEV void pass_qadd(const A &a, const D &d, int n)
-	{
-		ew_pairs(a, d, n, [](int, u32 x, u32 y) { return qadd4(x, y); });
-	}
-	template <class A, class D>
-	PDEV void pass_right(const A &a, const D &d, int n, const u32 *hs, const u32 *hz, u32 eb)
-	{
-		ew_pairs(a, d, n, [=](int t, u32 x, u32 y) {
-			u32 e = eb + (u32)(t / Q);
-			int i = pidx(e, t % Q), sh = (int)(e & 7);
-			return madd4(hs[i] << sh, hz[i] << sh, x, y);
-		});
-	}
-	// dispatch on where level `lvl` (source) and lvl-1 (destination) live
+	// dispatch on where level `lvl` (source) and lvl-1 (destination) live; KIND 0 = left,
+	// 1 = right (hrd = position of the decided left child), 2 = rate0_right / rep halving
 	template <int KIND>
 	PDEV void soft_pass(int lvl, u32 hrd)
 	{
 		int n = Q << (lvl - 1);
-		bool dst_lds = lvl - 1 <= RL;
-		u32 eb = dst_lds ? (hrd & (W - 1)) : hrd;
-#define POLAR_RUN(A, D, HS, HZ) \
-		do { \
-			if (KIND == 0) pass_left(A, D, n); \
-			else if (KIND == 1) pass_right(A, D, n, HS, HZ, eb); \
-			else pass_qadd(A, D, n); \
-		} while (0)
-		if (lvl == top) {
-			if (dst_lds)
-				POLAR_RUN(in, (Vec{sl + n}), hls, hlz);
+		if (lvl - 1 <= RL) {
+			u32 eb = hrd & (u32)(W - 1);
+			LVec d{sl + n};
+			if (lvl == top)
+				pass<KIND>(in, d, n, hls, hlz, eb);
+			else if (lvl > RL)
+				pass<KIND>(GVec{sg + 2 * n}, d, n, hls, hlz, eb);
 			else
-				POLAR_RUN(in, (Vec{sg + n}), hgs, hgz);
-		} else if (lvl > RL) {
-			if (dst_lds)
-				POLAR_RUN((Vec{sg + 2 * n}), (Vec{sl + n}), hls, hlz);
-			else
-				POLAR_RUN((Vec{sg + 2 * n}), (Vec{sg + n}), hgs, hgz);
+				pass<KIND>(LVec{sl + 2 * n}, d, n, hls, hlz, eb);
 		} else {
-			POLAR_RUN((Vec{sl + 2 * n}), (Vec{sl + n}), hls, hlz);
+			GVec d{sg + n};
+			if (lvl == top)
+				pass<KIND>(in, d, n, hgs, hgz, hrd);
+			else
+				pass<KIND>(GVec{sg + 2 * n}, d, n, hgs, hgz, hrd);
 		}
-#undef POLAR_RUN
 	}
 
-	// ---- generic (flat-pointer) accessors for the rarer node types ----
-	PDEV u32 soft_ld(int lvl, int i, int q) const
-	{
-		int t = i * Q + q;
-		if (lvl == top)
-			return in.ld(t);
-		if (lvl > RL)
-			return sg[(Q << lvl) + t];
-		return sl[(Q << lvl) + t];
-	}
-	struct Planes {
-		u32 *s, *z; // flat pointers
-		u32 eb;     // position of the node's first element inside the planes
-	};
-	PDEV Planes planes(int node_level, u32 hrd) const
-	{
-		Planes p;
-		if (node_level <= RL) {
-			p.s = hls; p.z = hlz; p.eb = hrd & (W - 1);
-		} else {
-			p.s = hgs; p.z = hgz; p.eb = hrd;
-		}
-		return p;
-	}
-	// byte-replicated mask of the `len` (< 8) elements starting at octet offset j0
-	static PDEV u32 span_mask(int j0, int len)
-	{
-		u32 b = (0xFFu >> j0) & ~(0xFFu >> (j0 + len));
-		return b * 0x01010101u;
-	}
-	// scratch below the node's own level (dead at a leaf, polar_decoder.hh:118): flat pointer to
-	// the level-`lvl` region, `lvl` < node level
-	PDEV u32 *tmp_region(int lvl) const
-	{
-		if (lvl > RL)
-			return sg + (Q << lvl);
-		return sl + (Q << lvl);
-	}
-	// scratch for a leaf-like node of `len` elements at level `lvl`: at least 4*max(1,len/8)*Q dwords
-	PDEV u32 *node_tmp(int lvl, int len) const { return len >= 8 ? tmp_region(lvl - 1) : tl; }
-
-	// comb / rate0_comb (polar_decoder.hh:52-67): node of level lvl at hrd; RATE0: left half is all +1
-	template <bool RATE0>
-	PDEV void comb(int lvl, u32 hrd)
+	// comb / rate0_comb (polar_decoder.hh:52-67): node of level lvl at hrd; RATE0: left half is all +1.
+	// c: the children's planes (c.eb = left child), o: the node's planes.
+	template <bool RATE0, class TC, class TO>
+	PDEV void comb(int lvl, Planes<TC> c, Planes<TO> o, bool inplace)
 	{
 		int h = 1 << (lvl - 1);
-		Planes c = planes(lvl - 1, hrd), o = planes(lvl, hrd);
 		if (h < 8) { // both halves share one octet (always in LDS: lvl <= 3)
 			int j0 = (int)(o.eb & 7);
 			u32 lowm = span_mask(j0, h);
@@ -343,23 +365,119 @@ struct Group {
 			}
 		} else {
 			int n = (h >> 3) * Q; // plane dwords per half
-			bool inplace = (lvl - 1 <= RL) == (lvl <= RL);
+			int il0 = pidx(c.eb, 0), ir0 = pidx(c.eb + h, 0), ol0 = pidx(o.eb, 0), or0 = pidx(o.eb + h, 0);
 			PFOR_LANES(lane) {
 				for (int t = lane; t < n; t += 64) {
-					int il = pidx(c.eb, 0) + t, ir = pidx(c.eb + h, 0) + t;
-					int ol = pidx(o.eb, 0) + t, orr = pidx(o.eb + h, 0) + t;
-					u32 rs = c.s[ir], rz = c.z[ir];
+					u32 rs = c.s[ir0 + t], rz = c.z[ir0 + t];
 					if (RATE0) {
-						o.s[ol] = rs;
-						o.z[ol] = rz;
+						o.s[ol0 + t] = rs;
+						o.z[ol0 + t] = rz;
 					} else {
-						o.s[ol] = c.s[il] ^ rs;
-						o.z[ol] = c.z[il] | rz;
+						o.s[ol0 + t] = c.s[il0 + t] ^ rs;
+						o.z[ol0 + t] = c.z[il0 + t] | rz;
 					}
 					if (!inplace) {
-						o.s[orr] = rs;
-						o.z[orr] = rz;
+						o.s[or0 + t] = rs;
+						o.z[or0 + t] = rz;
 					}
+				}
+			}
+		}
+		wave_sync();
+	}
+	template <bool RATE0>
+	PDEV void comb_any(int lvl, u32 hrd)
+	{
+		if (lvl <= RL)
+			comb<RATE0>(lvl, lplanes(hrd), lplanes(hrd), true);
+		else if (lvl == RL + 1)
+			comb<RATE0>(lvl, lplanes(hrd), gplanes(hrd), false);
+		else
+			comb<RATE0>(lvl, gplanes(hrd), gplanes(hrd), true);
+	}
+
+	// store a node's decision bits; s / z hold element j of the item at bit 7-j (normalised)
+	template <class T>
+	static PDEV void put_bits(const Planes<T> &p, int i, int j0, int len, u32 s, u32 z)
+	{
+		if (len >= 8) {
+			p.s[i] = s;
+			p.z[i] = z;
+		} else {
+			u32 m = span_mask(j0, len);
+			p.s[i] = bfi(m, s >> j0, p.s[i]);
+			p.z[i] = bfi(m, z >> j0, p.z[i]);
+		}
+	}
+
+	// message rows row.. for elements first..len-1 of one octet held in registers
+	PDEV void emit_octet(u32 s, u32 z, int len, int first, u32 row, int q) const
+	{
+#pragma unroll
+		for (int e = 0; e < 8; ++e)
+			if (e >= first && e < len)
+				out.st(row + (u32)(e - first), q, symbols(s << e, z << e));
+	}
+
+	// ---- leaves of at most 8 elements: one lane per frame quad, everything in registers ----
+	// rate0 / rate1 / rep / spc, polar_decoder.hh:68-75, 85-127
+	template <class SRC>
+	PDEV void leaf_small(u32 op, int lvl, const SRC &src, u32 hrd, u32 row)
+	{
+		int len = 1 << lvl;
+		Planes<lds_u32> p = lplanes(hrd);
+		int j0 = (int)(p.eb & 7);
+		PFOR_LANES(lane) {
+			if (lane < Q) {
+				int q = lane;
+				u32 x[8];
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					x[j] = j < len && op != OP_RATE0 ? src.ld(j * Q + q) : 0;
+				u32 s = 0, z = 0;
+				if (op == OP_REP) {
+#pragma unroll
+					for (int h = 4; h >= 1; h /= 2)
+						if (h < len) {
+#pragma unroll
+							for (int i = 0; i < 4; ++i)
+								if (i < h)
+									x[i] = qadd4(x[i], x[i + h]);
+						}
+					u32 zb = zero_bytes(x[0]);
+					s = byte_mask(x[0]);
+					z = byte_mask(zb);
+					out.st(row, q, symbols(x[0], zb));
+				} else if (op == OP_RATE1) {
+#pragma unroll
+					for (int j = 0; j < 8; ++j)
+						if (j < len) {
+							s |= (x[j] & SIGN_BITS) >> j;
+							z |= zero_bytes(x[j]) >> j;
+						}
+				} else if (op == OP_SPC) {
+					u32 mh = 0x7F007F00u, ml = 0x7F007F00u;
+#pragma unroll
+					for (int j = 0; j < 8; ++j)
+						if (j < len) {
+							s |= (x[j] & SIGN_BITS) >> j;
+							mh = pk_min(mh, abs_half(split_hi(x[j])));
+							ml = pk_min(ml, abs_half(split_lo(x[j])));
+						}
+					u32 odd = odd_mask(s);
+					if (odd) { // every position tied for the minimum takes the parity (polar_helper.hh:169-172)
+						u32 tie = 0;
+#pragma unroll
+						for (int j = 0; j < 8; ++j)
+							if (j < len)
+								tie |= tie_bits(x[j], mh, ml) >> j;
+						s ^= tie & odd;
+					}
+				}
+				put_bits(p, pidx(p.eb, q), j0, len, s, z);
+				if (op == OP_RATE1 || op == OP_SPC) {
+					trans_octet(s, z, len);
+					emit_octet(s, z, len, op == OP_SPC ? 1 : 0, row, q);
 				}
 			}
 		}
@@ -367,23 +485,13 @@ struct Group {
 	}
 
 	// polar transform of a node's decisions (trans, polar_decoder.hh:15-27) on bit planes held in
-	// ts / tz (nOct*Q dwords each, element 0 at bit 7), then emission of elements first..len-1
-	// as message rows row, row+1, ...
-	PDEV void trans_emit(u32 *ts, u32 *tz, int len, int first, u32 row)
+	// ts / tz (noct*Q dwords each, element 0 at bit 7), then emission of elements first..len-1
+	// as message rows row, row+1, ... (len >= 16)
+	template <class T>
+	PDEV void trans_emit(T *ts, T *tz, int len, int first, u32 row)
 	{
-		int noct = len >= 8 ? len >> 3 : 1;
+		int noct = len >> 3;
 		int n = noct * Q;
-		PFOR_LANES(lane) {
-			for (int t = lane; t < n; t += 64) {
-				u32 s = ts[t], z = tz[t];
-				if (len > 1) { s ^= (s << 1) & 0xAAAAAAAAu; z |= (z << 1) & 0xAAAAAAAAu; }
-				if (len > 2) { s ^= (s << 2) & 0xCCCCCCCCu; z |= (z << 2) & 0xCCCCCCCCu; }
-				if (len > 4) { s ^= (s << 4) & 0xF0F0F0F0u; z |= (z << 4) & 0xF0F0F0F0u; }
-				ts[t] = s;
-				tz[t] = z;
-			}
-		}
-		wave_sync();
 		for (int ho = 1; ho < noct; ho *= 2) { // stages h = 8*ho
 			PFOR_LANES(lane) {
 				for (int t = lane; t < n / 2; t += 64) {
@@ -406,96 +514,69 @@ struct Group {
 		wave_sync();
 	}
 
-	// store a node's decision bits; s / z hold element j of the item at bit 7-j (normalised)
-	static PDEV void put_bits(const Planes &p, int i, int j0, int len, u32 s, u32 z)
+	// ---- leaves of 16 elements and more: all lanes, one (octet, quad) item each ----
+	// tmp: 4*(len/8)*Q dwords of scratch (the dead LLR region below the node)
+	template <class SRC, class T>
+	PDEV void leaf_big(u32 op, int lvl, const SRC &src, Planes<T> p, T *tmp, u32 row)
 	{
-		if (len >= 8) {
-			p.s[i] = s;
-			p.z[i] = z;
-		} else {
-			u32 m = span_mask(j0, len);
-			p.s[i] = bfi(m, s >> j0, p.s[i]);
-			p.z[i] = bfi(m, z >> j0, p.z[i]);
-		}
-	}
-
-	// rate0 (polar_decoder.hh:68-75)
-	PDEV void rate0(int lvl, u32 hrd)
-	{
-		int len = 1 << lvl;
-		Planes p = planes(lvl, hrd);
-		int noct = len >= 8 ? len >> 3 : 1, j0 = (int)(p.eb & 7);
-		PFOR_LANES(lane) {
-			for (int t = lane; t < noct * Q; t += 64)
-				put_bits(p, pidx(p.eb, 0) + t, j0, len, 0, 0);
-		}
-		wave_sync();
-	}
-
-	// rate1 (polar_decoder.hh:85-93)
-	PDEV void rate1(int lvl, u32 hrd, u32 row)
-	{
-		int len = 1 << lvl;
-		Planes p = planes(lvl, hrd);
-		int noct = len >= 8 ? len >> 3 : 1, per = len >= 8 ? 8 : len, j0 = (int)(p.eb & 7);
-		u32 *ts = node_tmp(lvl, len), *tz = ts + noct * Q;
-		PFOR_LANES(lane) {
-			for (int t = lane; t < noct * Q; t += 64) {
-				int o = t / Q, q = t % Q;
-				u32 s = 0, z = 0;
-				for (int j = 0; j < per; ++j) {
-					u32 x = soft_ld(lvl, 8 * o + j, q);
-					s |= (x & SIGN_BITS) >> j;
-					z |= zero_bytes(x) >> j;
+		int len = 1 << lvl, noct = len >> 3, n = noct * Q;
+		int i0 = pidx(p.eb, 0);
+		if (op == OP_RATE0) {
+			PFOR_LANES(lane) {
+				for (int t = lane; t < n; t += 64) {
+					p.s[i0 + t] = 0;
+					p.z[i0 + t] = 0;
 				}
-				put_bits(p, pidx(p.eb, 0) + t, j0, len, s, z);
-				ts[t] = s;
-				tz[t] = z;
 			}
+			wave_sync();
+			return;
 		}
-		wave_sync();
-		trans_emit(ts, tz, len, 0, row);
-	}
-
-	// rep (polar_decoder.hh:94-106)
-	PDEV void rep(int lvl, u32 hrd, u32 row)
-	{
-		for (int l = lvl; l >= 1; --l)
-			soft_pass<2>(l, 0);
-		int len = 1 << lvl;
-		Planes p = planes(lvl, hrd);
-		int noct = len >= 8 ? len >> 3 : 1, j0 = (int)(p.eb & 7);
-		const u32 *s0 = tmp_region(0);
-		PFOR_LANES(lane) {
-			for (int t = lane; t < noct * Q; t += 64) {
-				int o = t / Q, q = t % Q;
-				u32 x = s0[q];
-				u32 s = byte_mask(x), z = byte_mask(zero_bytes(x));
-				put_bits(p, pidx(p.eb, 0) + t, j0, len, s, z);
-				if (o == 0)
-					out.st(row, q, symbols(x, zero_bytes(x)));
+		if (op == OP_REP) { // the halving passes have left the sum in the level-0 region
+			lds_u32 *s0 = sl + Q;
+			PFOR_LANES(lane) {
+				for (int t = lane; t < n; t += 64) {
+					int q = t % Q;
+					u32 x = s0[q], zb = zero_bytes(x);
+					p.s[i0 + t] = byte_mask(x);
+					p.z[i0 + t] = byte_mask(zb);
+					if (t < Q)
+						out.st(row, q, symbols(x, zb));
+				}
 			}
+			wave_sync();
+			return;
 		}
-		wave_sync();
-	}
-
-	// spc (polar_decoder.hh:107-127)
-	PDEV void spc(int lvl, u32 hrd, u32 row)
-	{
-		int len = 1 << lvl;
-		Planes p = planes(lvl, hrd);
-		int noct = len >= 8 ? len >> 3 : 1, per = len >= 8 ? 8 : len, j0 = (int)(p.eb & 7);
-		int n = noct * Q;
-		// scratch: per-item minima (2 dwords each), then the transform planes; per-quad results in tl
-		u32 *mins = node_tmp(lvl, len);
-		u32 *ts = mins + 2 * n, *tz = ts + n;
-		u32 *wk = tl + 4 * Q; // 3 dwords per quad
+		T *ts = tmp, *tz = tmp + n, *mins = tmp + 2 * n;
+		if (op == OP_RATE1) {
+			PFOR_LANES(lane) {
+				for (int t = lane; t < n; t += 64) {
+					int o = t / Q, q = t % Q;
+					u32 s = 0, z = 0;
+#pragma unroll
+					for (int j = 0; j < 8; ++j) {
+						u32 x = src.ld((8 * o + j) * Q + q);
+						s |= (x & SIGN_BITS) >> j;
+						z |= zero_bytes(x) >> j;
+					}
+					p.s[i0 + t] = s;
+					p.z[i0 + t] = z;
+					trans_octet(s, z, 8);
+					ts[t] = s;
+					tz[t] = z;
+				}
+			}
+			wave_sync();
+			trans_emit(ts, tz, len, 0, row);
+			return;
+		}
+		// spc (polar_decoder.hh:107-127)
 		PFOR_LANES(lane) {
 			for (int t = lane; t < n; t += 64) {
 				int o = t / Q, q = t % Q;
 				u32 s = 0, mh = 0x7F007F00u, ml = 0x7F007F00u;
-				for (int j = 0; j < per; ++j) {
-					u32 x = soft_ld(lvl, 8 * o + j, q);
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					u32 x = src.ld((8 * o + j) * Q + q);
 					s |= (x & SIGN_BITS) >> j;
 					mh = pk_min(mh, abs_half(split_hi(x)));
 					ml = pk_min(ml, abs_half(split_lo(x)));
@@ -506,7 +587,7 @@ struct Group {
 			}
 		}
 		wave_sync();
-		// per quad: weakest magnitude and parity over the whole node
+		lds_u32 *wk = tl; // per quad: weakest magnitude (2 dwords) and odd-parity mask
 		PFOR_LANES(lane) {
 			if (lane < Q) {
 				u32 mh = 0x7F007F00u, ml = 0x7F007F00u, px = 0;
@@ -516,31 +597,27 @@ struct Group {
 					ml = pk_min(ml, mins[2 * t + 1]);
 					px ^= ts[t];
 				}
-				px ^= (px >> 4) & 0x0F0F0F0Fu;
-				px ^= (px >> 2) & 0x03030303u;
-				px ^= (px >> 1) & 0x01010101u;
 				wk[3 * lane] = mh;
 				wk[3 * lane + 1] = ml;
-				wk[3 * lane + 2] = (px & 0x01010101u) * 0xFFu; // all 8 element bits of the odd-parity frames
+				wk[3 * lane + 2] = odd_mask(px);
 			}
 		}
 		wave_sync();
-		// every position tied for the minimum is multiplied by the parity (polar_helper.hh:169-172)
 		PFOR_LANES(lane) {
 			for (int t = lane; t < n; t += 64) {
 				int o = t / Q, q = t % Q;
 				u32 wh = wk[3 * q], wl = wk[3 * q + 1], odd = wk[3 * q + 2];
-				u32 s = ts[t];
+				u32 s = ts[t], z = 0;
 				if (odd) {
 					u32 tie = 0;
-					for (int j = 0; j < per; ++j) {
-						u32 x = soft_ld(lvl, 8 * o + j, q);
-						u32 eq = eq_half(abs_half(split_hi(x)), wh) | (eq_half(abs_half(split_lo(x)), wl) >> 8);
-						tie |= eq >> j;
-					}
+#pragma unroll
+					for (int j = 0; j < 8; ++j)
+						tie |= tie_bits(src.ld((8 * o + j) * Q + q), wh, wl) >> j;
 					s ^= tie & odd;
 				}
-				put_bits(p, pidx(p.eb, 0) + t, j0, len, s, 0);
+				p.s[i0 + t] = s;
+				p.z[i0 + t] = 0;
+				trans_octet(s, z, 8);
 				ts[t] = s;
 				tz[t] = 0;
 			}
@@ -549,71 +626,122 @@ struct Group {
 		trans_emit(ts, tz, len, 1, row);
 	}
 
-	// rate1_comb (polar_decoder.hh:76-84): node of level lvl at hrd, left child decided
-	PDEV void rate1_comb(int lvl, u32 hrd, u32 row)
+	PDEV void leaf(u32 op, int lvl, u32 hrd, u32 row)
+	{
+		if (op == OP_REP && lvl > 3)
+			for (int l = lvl; l >= 1; --l)
+				soft_pass<2>(l, 0);
+		int n4 = Q << (lvl - 1); // 4 * (len/8) * Q: the whole level lvl-1 region
+		if (lvl <= 3) {
+			if (lvl == top)
+				leaf_small(op, lvl, in, hrd, row);
+			else
+				leaf_small(op, lvl, LVec{sl + (Q << lvl)}, hrd, row);
+		} else if (lvl <= RL) {
+			if (lvl == top)
+				leaf_big(op, lvl, in, lplanes(hrd), sl + n4, row);
+			else
+				leaf_big(op, lvl, LVec{sl + (Q << lvl)}, lplanes(hrd), sl + n4, row);
+		} else {
+			leaf_big(op, lvl, any_src(lvl), fplanes(lvl, hrd), fregion(lvl - 1), row);
+		}
+	}
+
+	// rate1_comb (polar_decoder.hh:76-84): node of level lvl at hrd, left child decided.
+	// c: children's planes (left child at c.eb), o: the node's planes, tmp: 2*max(1,h/8)*Q dwords
+	template <class SRC, class TC, class TO, class T>
+	PDEV void rate1_comb(int lvl, const SRC &src, Planes<TC> c, Planes<TO> o, T *tmp, u32 row)
 	{
 		int h = 1 << (lvl - 1);
-		Planes c = planes(lvl - 1, hrd), o = planes(lvl, hrd);
 		int noct = h >= 8 ? h >> 3 : 1, per = h >= 8 ? 8 : h;
 		int n = noct * Q;
-		u32 *ts = node_tmp(lvl - 1, h), *tz = ts + n; // the left child's LLR region is dead by now
+		T *ts = tmp, *tz = tmp + n;
 		int j0 = (int)(o.eb & 7); // nonzero only when the whole node fits one octet
+		int il0 = pidx(c.eb, 0), ol0 = pidx(o.eb, 0), or0 = pidx(o.eb + h, 0);
 		PFOR_LANES(lane) {
 			for (int t = lane; t < n; t += 64) {
 				int oc = t / Q, q = t % Q;
-				int il = pidx(c.eb, 0) + t;
-				u32 ls = c.s[il], lz = c.z[il];
+				u32 ls = c.s[il0 + t], lz = c.z[il0 + t];
 				u32 rs = 0, rz = 0;
-				for (int j = 0; j < per; ++j) {
-					int i = 8 * oc + j;
-					int sh = h >= 8 ? j : j0 + j;
-					u32 r = madd4(ls << sh, lz << sh, soft_ld(lvl, i, q), soft_ld(lvl, i + h, q));
-					rs |= (r & SIGN_BITS) >> j;
-					rz |= zero_bytes(r) >> j;
-				}
-				ts[t] = rs;
-				tz[t] = rz;
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					if (j < per) {
+						int i = 8 * oc + j;
+						int sh = h >= 8 ? j : j0 + j;
+						u32 r = madd4(ls << sh, lz << sh, src.ld(i * Q + q), src.ld((i + h) * Q + q));
+						rs |= (r & SIGN_BITS) >> j;
+						rz |= zero_bytes(r) >> j;
+					}
 				if (h >= 8) {
-					o.s[pidx(o.eb, 0) + t] = ls ^ rs;
-					o.z[pidx(o.eb, 0) + t] = lz | rz;
-					o.s[pidx(o.eb + h, 0) + t] = rs;
-					o.z[pidx(o.eb + h, 0) + t] = rz;
+					o.s[ol0 + t] = ls ^ rs;
+					o.z[ol0 + t] = lz | rz;
+					o.s[or0 + t] = rs;
+					o.z[or0 + t] = rz;
 				} else {
 					u32 lm = span_mask(j0, h), rm = span_mask(j0 + h, h);
 					u32 s = ls ^ ((rs >> j0) & lm), z = lz | ((rz >> j0) & lm);
 					s = bfi(rm, rs >> (j0 + h), s);
 					z = bfi(rm, rz >> (j0 + h), z);
-					o.s[il] = s;
-					o.z[il] = z;
+					o.s[ol0 + t] = s;
+					o.z[ol0 + t] = z;
+				}
+				trans_octet(rs, rz, per);
+				if (h <= 8) {
+					emit_octet(rs, rz, h, 0, row, q);
+				} else {
+					ts[t] = rs;
+					tz[t] = rz;
 				}
 			}
 		}
 		wave_sync();
-		trans_emit(ts, tz, h, 0, row);
+		if (h > 8)
+			trans_emit(ts, tz, h, 0, row);
+	}
+	PDEV void rate1_comb_any(int lvl, u32 hrd, u32 row)
+	{
+		// scratch: the left child's LLR region (level lvl-1), dead by now
+		if (lvl <= RL) {
+			lds_u32 *tmp = sl + (Q << (lvl - 1));
+			if (lvl == top)
+				rate1_comb(lvl, in, lplanes(hrd), lplanes(hrd), tmp, row);
+			else
+				rate1_comb(lvl, LVec{sl + (Q << lvl)}, lplanes(hrd), lplanes(hrd), tmp, row);
+		} else {
+			rate1_comb(lvl, any_src(lvl), fplanes(lvl - 1, hrd), fplanes(lvl, hrd), fregion(lvl - 1), row);
+		}
 	}
 
-	// the interpreter (polar_decoder.hh:131-464)
 	template <class P>
-	PDEV void run(const P *prog)
+	static PDEV DevOp fetch(P prog, int pc)
 	{
-		for (int pc = 0;; ++pc) {
-			u32 w = prog[pc].op_level, hrd = prog[pc].hrd, row = prog[pc].row;
-			u32 op = w & 255;
-			int lvl = (int)(w >> 8);
+		DevOp d;
+		d.op_level = prog[pc].op_level;
+		d.hrd = prog[pc].hrd;
+		d.row = prog[pc].row;
+		d.pad = 0;
+		return d;
+	}
+
+	// the interpreter (polar_decoder.hh:131-464); prog is terminated by two OP_END words
+	template <class P>
+	PDEV void run(P prog)
+	{
+		DevOp cur = fetch(prog, 0);
+		for (int pc = 1;; ++pc) {
+			u32 op = cur.op_level & 255, hrd = cur.hrd, row = cur.row;
+			int lvl = (int)(cur.op_level >> 8);
 			if (op == OP_END)
 				break;
+			cur = fetch(prog, pc); // fetched while the current node runs
 			switch (op) {
 			case OP_LEFT: soft_pass<0>(lvl, hrd); break;
 			case OP_RIGHT: soft_pass<1>(lvl, hrd); break;
 			case OP_RATE0_RIGHT: soft_pass<2>(lvl, hrd); break;
-			case OP_COMB: comb<false>(lvl, hrd); break;
-			case OP_RATE0_COMB: comb<true>(lvl, hrd); break;
-			case OP_RATE0: rate0(lvl, hrd); break;
-			case OP_RATE1: rate1(lvl, hrd, row); break;
-			case OP_REP: rep(lvl, hrd, row); break;
-			case OP_SPC: spc(lvl, hrd, row); break;
-			case OP_RATE1_COMB: rate1_comb(lvl, hrd, row); break;
-			default: break;
+			case OP_COMB: comb_any<false>(lvl, hrd); break;
+			case OP_RATE0_COMB: comb_any<true>(lvl, hrd); break;
+			case OP_RATE1_COMB: rate1_comb_any(lvl, hrd, row); break;
+			default: leaf(op, lvl, hrd, row); break;
 			}
 		}
 	}

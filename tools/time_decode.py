@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Time the decode kernel for any code size on the all-(+1) codeword + AWGN (the decoder is
+symmetric, so this is representative). Prints frames/s and kernel ms.
+  python3 tools/time_decode.py --M 16 --frames 32768 --fpw 32 --lds-level 7"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser()
+ap.add_argument("--M", type=int, default=16)
+ap.add_argument("--frames", type=int, default=32768)
+ap.add_argument("--fpw", type=int, default=0)
+ap.add_argument("--lds-level", type=int, default=0)
+ap.add_argument("--waves", type=int, default=0)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--snr", type=float, default=-1.0)
+a = ap.parse_args()
+import torch
+import polar_amd
+
+N = 1 << a.M
+fro = np.zeros(N, np.uint8)
+polar_amd.PolarCodeConst0()(fro, a.M, N // 2, polar_amd.testbench_probability())
+prog = np.zeros(2 * N + 1, np.uint8)
+n = polar_amd.PolarCompiler()(prog, fro, a.M)
+prog = prog[:n].copy()
+sess = polar_amd.Session(0)
+sess.configure(a.fpw, a.lds_level, a.waves)
+sigma = float(np.sqrt(1.0 / (2.0 * 10.0 ** (a.snr / 10.0))))
+g = torch.Generator(device="cuda").manual_seed(1)
+llr = torch.empty((N, a.frames), dtype=torch.int8, device="cuda")
+rows = max(1, min(N, (1 << 28) // a.frames))
+for r in range(0, N, rows):
+    y = 1.0 + sigma * torch.randn((min(rows, N - r), a.frames), generator=g, device="cuda")
+    llr[r:r + rows] = torch.clamp(torch.round(y * (2.0 / sigma**2)), -128, 127).to(torch.int8)
+out = torch.empty((N // 2, a.frames), dtype=torch.int8, device="cuda")
+dec = polar_amd.PolarDecoder(sess)
+ms = []
+for _ in range(a.reps):
+    dec(out, llr, prog)
+    ms.append(sess.last_decode_ms())
+best = min(ms)
+err = float((out != 1).float().mean())
+print("M %d frames %d fpw %d rl %d waves %d: kernel_ms %.2f  %.3f Mframes/s  %.1f Gbit/s info  frac %.4f  ber %.2e" % (
+    a.M, a.frames, a.fpw, a.lds_level, a.waves, best, a.frames / best / 1e3, a.frames * (N // 2) / best / 1e6,
+    a.frames * 1.5 * N / (best * 1e-3) / 8e12, err), flush=True)
