@@ -413,9 +413,9 @@ extern "C" int polar_hip_load_program(polar_hip_handle *h, const uint8_t *progra
 static const KernelVariant *pick_variant(const polar_hip_handle *h, int top)
 {
 	int fpw = h->cfg_frames_per_wave, rl = h->cfg_lds_level;
-	if (!fpw) { // defaults: the ~20 KB family
-		fpw = 16;
-		rl = 9;
+	if (!fpw) { // default: most resident wavefronts (measured best at N = 2^16)
+		fpw = 64;
+		rl = 6;
 		(void)top;
 	}
 	for (const KernelVariant &v : g_variants)

@@ -1,11 +1,11 @@
 #!/bin/bash
 # rocprofv3 passes for the decode kernel; one counter group per run (MI355X_MICROARCH.md: PMC slots)
-set -e
-F=${1:-32768}; G=${2:-32}; L=${3:-7}; TAG=${4:-r1}
+# usage: tools/prof_pmc.sh M FRAMES FPW LDS_LEVEL TAG
+M=${1:-16}; F=${2:-32768}; G=${3:-32}; L=${4:-7}; TAG=${5:-r1}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="tools/prof_run.py --frames $F --fpw $G --lds-level $L --reps 2"
+ARGS="tools/time_decode.py --M $M --frames $F --fpw $G --lds-level $L --reps 2"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
