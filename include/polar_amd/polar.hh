@@ -1,0 +1,151 @@
+// polar_amd/polar.hh -- drop-in C++ templates with the reference's class names and functor
+// signatures, forwarding to the C ABI of libpolar_hip.so (include/polar_hip.h).
+//
+//   PolarEncoder<TYPE,M>::operator()(TYPE *codeword, const TYPE *message, const uint8_t *frozen)   polar_encoder.hh:15
+//   PolarSysEnc<TYPE,M>::operator()(same)                                                         polar_encoder.hh:36
+//   PolarDecoder<TYPE,MAX_M>::operator()(TYPE *message, const TYPE *codeword, const uint8_t *program)  polar_decoder.hh:131
+//   PolarCompiler::operator()(uint8_t *program, const uint8_t *frozen, int level) -> length      polar_compiler.hh:51
+//   PolarFreezer::operator()(uint8_t *frozen, int level, long double p = 0.5L, long double th = 0.5L) -> K   polar_freezer.hh:23
+//   PolarCodeConst0<MAX_M>::operator()(uint8_t *frozen, int level, int K, long double p = exp(-1.L))  polar_freezer.hh:49
+//
+// TYPE = GPU<int8_t, W>: a lane bundle of W frames, laid out exactly like the reference's
+// SIMD<int8_t, W> (W consecutive bytes = one code element of W frames, testbench.cc:134-139),
+// so caller code that sizes and casts buffers with sizeof(TYPE) keeps working; W is no longer
+// limited by a vector register (thousands to millions of frames per call).
+//
+// The reference has no error channel; misuse trips assert. Same here: a failing C ABI call
+// prints polar_hip_last_error() and aborts.
+#pragma once
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <cmath>
+
+#include "../polar_hip.h"
+
+template <typename VALUE, int WIDTH>
+struct GPU {
+	static const int SIZE = WIDTH;
+	VALUE v[WIDTH];
+};
+
+namespace polar_amd_detail {
+inline void check(int rc, const char *what)
+{
+	if (rc < 0) {
+		fprintf(stderr, "%s failed (%d): %s\n", what, rc, polar_hip_last_error());
+		abort();
+	}
+}
+// one device context per host thread, created on first use (device from POLAR_HIP_DEVICE)
+inline polar_hip_handle *context()
+{
+	static thread_local polar_hip_handle *h = nullptr;
+	if (!h) {
+		const char *dev = getenv("POLAR_HIP_DEVICE");
+		check(polar_hip_create(&h, dev ? atoi(dev) : 0), "polar_hip_create");
+	}
+	return h;
+}
+}
+
+class PolarCompiler
+{
+public:
+	int operator()(uint8_t *program, const uint8_t *frozen, int level)
+	{
+		int n = polar_compile(program, frozen, level);
+		polar_amd_detail::check(n, "PolarCompiler");
+		return n;
+	}
+};
+
+class PolarFreezer
+{
+public:
+	int operator()(uint8_t *frozen_bits, int level, long double erasure_probability = 0.5L, long double freezing_threshold = 0.5L)
+	{
+		int K = polar_freezer(frozen_bits, level, erasure_probability, freezing_threshold);
+		polar_amd_detail::check(K, "PolarFreezer");
+		return K;
+	}
+};
+
+template <int MAX_M>
+class PolarCodeConst0
+{
+public:
+	void operator()(uint8_t *frozen_bits, int level, int K, long double erasure_probability = std::exp(-1.L))
+	{
+		if (level > MAX_M)
+			polar_amd_detail::check(POLAR_E_ARG, "PolarCodeConst0: level > MAX_M");
+		polar_amd_detail::check(polar_code_const0(frozen_bits, level, K, erasure_probability), "PolarCodeConst0");
+	}
+};
+
+template <typename TYPE, int M>
+class PolarEncoder;
+template <typename TYPE, int M>
+class PolarSysEnc;
+template <typename TYPE, int MAX_M>
+class PolarDecoder;
+
+template <int W, int M>
+class PolarEncoder<GPU<int8_t, W>, M>
+{
+	typedef GPU<int8_t, W> TYPE;
+public:
+	void operator()(TYPE *codeword, const TYPE *message, const uint8_t *frozen)
+	{
+		polar_amd_detail::check(polar_hip_encode(polar_amd_detail::context(), 0, (int8_t *)codeword, (const int8_t *)message, frozen, M, W, POLAR_HOST), "PolarEncoder");
+	}
+};
+
+template <int W, int M>
+class PolarSysEnc<GPU<int8_t, W>, M>
+{
+	typedef GPU<int8_t, W> TYPE;
+public:
+	void operator()(TYPE *codeword, const TYPE *message, const uint8_t *frozen)
+	{
+		polar_amd_detail::check(polar_hip_encode(polar_amd_detail::context(), 1, (int8_t *)codeword, (const int8_t *)message, frozen, M, W, POLAR_HOST), "PolarSysEnc");
+	}
+};
+
+// The reference object carries soft[2N] / hard[N] (polar_decoder.hh:128-129) and is allocated
+// by the caller; here the scratch lives on the device behind the thread's context, and the
+// last program is kept resident so repeated calls (testbench.cc:171) do not re-upload it.
+template <int W, int MAX_M>
+class PolarDecoder<GPU<int8_t, W>, MAX_M>
+{
+	typedef GPU<int8_t, W> TYPE;
+	const uint8_t *last_program = nullptr;
+	uint64_t last_digest = 0;
+	int program_id = -1;
+	static int length_of(const uint8_t *program)
+	{
+		int n = 1;
+		while (program[n] != 255)
+			++n;
+		return n + 1;
+	}
+public:
+	void operator()(TYPE *message, const TYPE *codeword, const uint8_t *program)
+	{
+		if (program[0] > MAX_M)
+			polar_amd_detail::check(POLAR_E_ARG, "PolarDecoder: level > MAX_M (polar_decoder.hh:135)");
+		int n = length_of(program);
+		uint64_t dg = 0xcbf29ce484222325ull;
+		for (int i = 0; i < n; ++i)
+			dg = (dg ^ program[i]) * 0x100000001b3ull;
+		if (program_id < 0 || program != last_program || dg != last_digest) {
+			program_id = polar_hip_load_program(polar_amd_detail::context(), program, n);
+			polar_amd_detail::check(program_id, "PolarDecoder (program)");
+			last_program = program;
+			last_digest = dg;
+		}
+		polar_amd_detail::check(polar_hip_decode(polar_amd_detail::context(), program_id, (int8_t *)message, (const int8_t *)codeword, W, POLAR_HOST), "PolarDecoder");
+	}
+};

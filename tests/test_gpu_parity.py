@@ -214,3 +214,17 @@ def test_counters(session, oracle):
         else:
             session.count(d, tn, to, None, None)
         assert d.cpu().tolist() == exp.tolist()
+
+
+def test_cpp_dropin_header():
+    """include/polar_amd/polar.hh: the reference bench's call sequence with TYPE = GPU<int8_t, W>
+    (tests/cpp/dropin_test.cc, built by __graft_entry__.build())."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "dropin ok" in r.stdout, r.stdout + r.stderr

@@ -169,3 +169,13 @@ def test_emulated_core_golden_digest(emu, oracle, golden):
         llr = family_llr(k["family"], k["llr_seed"], cw)
         assert "%016x" % fnv1a64(_emu_decode(emu, llr, prog, 4, 9)) == k["out_fnv"]
         assert "%016x" % fnv1a64(_emu_decode(emu, llr, prog, 16, 7)) == k["out_fnv"]
+
+
+def test_cpp_dropin_header_compiles():
+    """The drop-in header is plain C++17 over the C ABI: it must compile and link on the host."""
+    import subprocess
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as d:
+        subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"),
+                        os.path.join(ROOT, "tests", "cpp", "dropin_test.cc"), "-L" + os.path.join(ROOT, "polar_amd"), "-lpolar_hip"], check=True)
