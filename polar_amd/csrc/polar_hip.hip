@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -46,10 +47,9 @@ struct DecodeArgs {
 	uint8_t *msg;
 	u32 *scratch;          // per-block arenas, block_dwords each
 	size_t block_dwords;
-	size_t frames;
+	size_t stride;         // bytes per row of cw and msg: a multiple of 4, groups * 4Q <= stride
 	u32 groups;
 	int top;
-	int aligned;           // cw and msg are 4-byte aligned
 };
 
 // Persistent wavefronts: block b walks the groups b, b + gridDim, ... Blocks are dealt to
@@ -78,11 +78,8 @@ __global__ void __launch_bounds__(64) sc_decode_kernel(DecodeArgs a)
 		if (grp >= a.groups)
 			continue;
 		size_t g0 = (size_t)grp * (4 * Q);
-		size_t left = a.frames - g0;
-		int valid = left < (size_t)(4 * Q) ? (int)left : 4 * Q;
-		bool fast = a.aligned && valid == 4 * Q && a.frames % 4 == 0;
-		g.in = InVec<Q>{a.cw + g0, a.frames, valid, fast};
-		g.out = OutRows<Q>{a.msg + g0, a.frames, valid, fast};
+		g.in = InVec<Q>{a.cw + g0, a.stride};
+		g.out = OutRows<Q>{a.msg + g0, a.stride};
 		g.run((prog_ptr)a.prog);
 	}
 }
@@ -260,8 +257,9 @@ struct DeviceBuffer {
 };
 
 struct LoadedProgram {
-	HostProgram host;
-	DevOp *dev = nullptr;
+	HostProgram host;                // unfused translation: level, rows, validation
+	std::vector<uint8_t> bytes;      // the reference byte-code as loaded
+	std::map<int, DevOp *> dev;      // device instruction stream per frame-quads-per-wave (fusion depends on it)
 };
 
 struct polar_hip_handle {
@@ -271,7 +269,7 @@ struct polar_hip_handle {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool timed = false;
 	std::vector<LoadedProgram> programs;
-	DeviceBuffer scratch, stage_in, stage_out, enc_tmp, tables, counters;
+	DeviceBuffer scratch, stage_in, stage_out, enc_tmp, tables, counters, pad_in, pad_out;
 	std::vector<uint8_t> frozen_cache; // frozen set the device tables were built from
 	int cfg_frames_per_wave = 0, cfg_lds_level = 0, cfg_max_waves = 0;
 };
@@ -360,14 +358,16 @@ extern "C" void polar_hip_destroy(polar_hip_handle *h)
 	(void)hipSetDevice(h->device);
 	(void)hipStreamSynchronize(h->stream);
 	for (auto &p : h->programs)
-		if (p.dev)
-			(void)hipFree(p.dev);
+		for (auto &d : p.dev)
+			(void)hipFree(d.second);
 	h->scratch.release();
 	h->stage_in.release();
 	h->stage_out.release();
 	h->enc_tmp.release();
 	h->tables.release();
 	h->counters.release();
+	h->pad_in.release();
+	h->pad_out.release();
 	(void)hipEventDestroy(h->ev0);
 	(void)hipEventDestroy(h->ev1);
 	(void)hipStreamDestroy(h->stream);
@@ -401,11 +401,7 @@ extern "C" int polar_hip_load_program(polar_hip_handle *h, const uint8_t *progra
 	int err = translate_program(program, length, lp.host);
 	if (err)
 		return fail(POLAR_E_PROGRAM, "polar_hip_load_program: malformed program (rule " + std::to_string(err) + ")");
-	if (use_device(h))
-		return POLAR_E_HIP;
-	size_t bytes = lp.host.ops.size() * sizeof(DevOp);
-	HIP_TRY(hipMalloc((void **)&lp.dev, bytes));
-	HIP_TRY(hipMemcpy(lp.dev, lp.host.ops.data(), bytes, hipMemcpyHostToDevice));
+	lp.bytes.assign(program, program + length);
 	h->programs.push_back(lp);
 	return (int)h->programs.size() - 1;
 }
@@ -424,19 +420,45 @@ static const KernelVariant *pick_variant(const polar_hip_handle *h, int top)
 	return nullptr;
 }
 
+// Enqueues the decode of `frames` frames on `stream`. The kernel wants whole groups of 4Q frames
+// and dword-aligned rows; anything else is staged through padded device copies (zero-filled
+// tail frames decode to garbage that is never copied back).
 static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, hipStream_t stream, bool timed)
 {
-	const LoadedProgram &lp = h->programs[program_id];
+	LoadedProgram &lp = h->programs[program_id];
 	const KernelVariant *v = pick_variant(h, lp.host.top);
 	if (!v)
 		return fail(POLAR_E_ARG, "no kernel variant for the configured (frames_per_wave, lds_level)");
-	const int fpw = 4 * v->q;
+	if (!lp.dev.count(v->q)) { // first use with this wavefront shape: fuse and upload
+		HostProgram hp;
+		if (translate_program(lp.bytes.data(), (int)lp.bytes.size(), hp, v->q))
+			return fail(POLAR_E_PROGRAM, "program translation failed");
+		DevOp *d = nullptr;
+		size_t bytes = hp.ops.size() * sizeof(DevOp);
+		HIP_TRY(hipMalloc((void **)&d, bytes));
+		HIP_TRY(hipMemcpy(d, hp.ops.data(), bytes, hipMemcpyHostToDevice));
+		lp.dev[v->q] = d;
+	}
+	const size_t fpw = 4 * (size_t)v->q, n = (size_t)1 << lp.host.top, rows = lp.host.rows;
 	size_t groups = (frames + fpw - 1) / fpw;
 	if (groups > 0x7FFFFFFFu)
 		return fail(POLAR_E_ARG, "too many frames for one call");
 	h->timed = false;
 	if (!groups)
 		return POLAR_OK;
+	const size_t padded = groups * fpw;
+	const bool direct = padded == frames && (uintptr_t)codeword % 4 == 0 && (uintptr_t)message % 4 == 0;
+	const uint8_t *cw = (const uint8_t *)codeword;
+	uint8_t *msg = (uint8_t *)message;
+	int rc;
+	if (!direct) {
+		if ((rc = h->pad_in.reserve(n * padded)) || (rc = h->pad_out.reserve((rows ? rows : 1) * padded)))
+			return rc;
+		HIP_TRY(hipMemsetAsync(h->pad_in.p, 0, n * padded, stream));
+		HIP_TRY(hipMemcpy2DAsync(h->pad_in.p, padded, codeword, frames, frames, n, hipMemcpyDeviceToDevice, stream));
+		cw = (const uint8_t *)h->pad_in.p;
+		msg = (uint8_t *)h->pad_out.p;
+	}
 	int per_cu = 0;
 	HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->fn, 64, 0));
 	if (per_cu < 1)
@@ -449,20 +471,18 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	if (blocks >= 8)
 		blocks -= blocks % 8;
 	DecodeArgs a;
-	a.prog = lp.dev;
-	a.cw = (const uint8_t *)codeword;
-	a.msg = (uint8_t *)message;
-	a.frames = frames;
+	a.prog = lp.dev[v->q];
+	a.cw = cw;
+	a.msg = msg;
+	a.stride = padded;
 	a.groups = (u32)groups;
 	a.top = lp.host.top;
-	a.aligned = ((uintptr_t)codeword % 4 == 0) && ((uintptr_t)message % 4 == 0);
 	a.scratch = nullptr;
 	a.block_dwords = 0;
 	if (lp.host.top > v->rl) {
 		size_t soft = (size_t)v->q << lp.host.top;
 		a.block_dwords = soft + 2 * (soft / 8);
-		int rc = h->scratch.reserve(blocks * a.block_dwords * sizeof(u32));
-		if (rc)
+		if ((rc = h->scratch.reserve(blocks * a.block_dwords * sizeof(u32))))
 			return rc;
 		a.scratch = (u32 *)h->scratch.p;
 	}
@@ -474,6 +494,8 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 		HIP_TRY(hipEventRecord(h->ev1, stream));
 		h->timed = true;
 	}
+	if (!direct && rows)
+		HIP_TRY(hipMemcpy2DAsync(message, frames, msg, padded, frames, rows, hipMemcpyDeviceToDevice, stream));
 	return POLAR_OK;
 }
 

@@ -42,8 +42,17 @@ typedef uint32_t u32;
 
 enum : u32 {
 	OP_LEFT = 0, OP_RIGHT = 1, OP_COMB = 2, OP_RATE0 = 3, OP_RATE1 = 4, OP_REP = 5, OP_SPC = 6,
-	OP_RATE0_RIGHT = 7, OP_RATE0_COMB = 8, OP_RATE1_COMB = 9, OP_END = 255
+	OP_RATE0_RIGHT = 7, OP_RATE0_COMB = 8, OP_RATE1_COMB = 9,
+	// device-only: a run of left / right / rate0_right nodes descending level by level, fused by
+	// the host into one pass (program.hpp); `pad` holds depth and stage kinds
+	OP_CHAIN = 16,
+	OP_END = 255
 };
+enum { CHAIN_MAX = 3 };
+// DevOp.pad of OP_CHAIN: bits 0-1 depth D, bits 2-3 kind of stage 1 (0 = f, 1 = g, 2 = qadd),
+// bit 3+k kind of stage k >= 2 (0 = f, 1 = qadd), bit 8+k: output of stage k is not stored (it
+// only feeds a rate0_right stage of the same chain)
+
 
 // Device instruction word: the reference byte-code with the interpreter's running state
 // (lvl / hrd / msg of polar_decoder.hh:133-134) resolved at load time by the host.
@@ -56,7 +65,16 @@ struct alignas(16) DevOp {
 
 #ifndef POLAR_EMU
 #define PDEV __device__ __forceinline__
-#define PFOR_LANES(lane) for (int lane = (int)(threadIdx.x & 63), once_ = 1; once_; once_ = 0)
+// The lane id is re-materialised (opaque to the optimiser) in every parallel region: otherwise
+// LICM hoists the per-lane address arithmetic of every node type out of the interpreter loop
+// and the kernel needs > 300 VGPRs.
+__device__ __forceinline__ int lane_id_()
+{
+	int l = (int)(threadIdx.x & 63);
+	asm volatile("" : "+v"(l));
+	return l;
+}
+#define PFOR_LANES(lane) for (int lane = lane_id_(), once_ = 1; once_; once_ = 0)
 typedef short v2s_ __attribute__((ext_vector_type(2)));
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) u32 lds_u32;
@@ -72,6 +90,10 @@ PDEV u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, se
 // instructions in order, so only the compiler has to be kept from reordering.
 PDEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 #endif
+
+PDEV int chain_depth(u32 pad) { return (int)(pad & 3); }
+PDEV int chain_kind(u32 pad, int k) { return k == 1 ? (int)((pad >> 2) & 3) : ((pad >> (3 + k)) & 1 ? 2 : 0); }
+PDEV bool chain_skip(u32 pad, int k) { return (pad >> (8 + k)) & 1; }
 
 PDEV u32 bfi(u32 mask, u32 a, u32 b) { return ((a ^ b) & mask) ^ b; } // mask ? a : b (v_bfi_b32)
 
@@ -161,6 +183,10 @@ PDEV u32 odd_mask(u32 px)
 	return (px & 0x01010101u) * 0xFFu;
 }
 
+// component-wise forms for 16-byte accesses
+PDEV u32x4 prod4(u32x4 a, u32x4 b) { u32x4 r; r.x = prod4(a.x, b.x); r.y = prod4(a.y, b.y); r.z = prod4(a.z, b.z); r.w = prod4(a.w, b.w); return r; }
+PDEV u32x4 qadd4(u32x4 a, u32x4 b) { u32x4 r; r.x = qadd4(a.x, b.x); r.y = qadd4(a.y, b.y); r.z = qadd4(a.z, b.z); r.w = qadd4(a.w, b.w); return r; }
+
 // ---- memory views ----
 
 struct GVec { // linear dword array in the HBM scratch arena
@@ -179,30 +205,26 @@ struct LVec { // linear dword array in LDS
 	PDEV void st4(int t, u32x4 v) const { *reinterpret_cast<lds_u32x4 *>(p + t) = v; }
 };
 
-// the caller's codeword buffer: row i of the group starts at in + i*stride (bytes)
+// the caller's codeword buffer: row i of the group starts at p + i*stride (bytes). The host
+// guarantees dword-aligned rows and whole groups (ragged batches are staged through a padded
+// copy, polar_hip.hip), so a row segment of the group is Q aligned dwords.
 template <int Q> struct InVec {
 	const uint8_t *p; // first byte of the group's frames in row 0
-	size_t stride;    // total frames (bytes per row)
-	int valid;        // frames of this group that exist (<= 4*Q)
-	bool fast;        // rows dword-aligned and group complete
+	size_t stride;    // bytes per row
 	PDEV u32 ld(int t) const
 	{
 		int i = t / Q, q = t % Q;
-		const uint8_t *r = p + (size_t)i * stride + 4 * q;
-		if (fast)
-			return *reinterpret_cast<const u32 *>(r);
-		return ld_slow(r, q);
-	}
-	PDEV u32 ld_slow(const uint8_t *r, int q) const
-	{
-		u32 v = 0;
-		for (int k = 0; k < 4; ++k)
-			if (4 * q + k < valid)
-				v |= (u32)r[k] << (8 * k);
-		return v;
+		return *reinterpret_cast<const u32 *>(p + (size_t)i * stride + 4 * q);
 	}
 	PDEV u32x4 ld4(int t) const
 	{
+		if (Q % 4 == 0) { // four consecutive quads of one row
+			int i = t / Q, q = t % Q;
+			const u32 *r = reinterpret_cast<const u32 *>(p + (size_t)i * stride + 4 * q);
+			u32x4 v;
+			v.x = r[0]; v.y = r[1]; v.z = r[2]; v.w = r[3];
+			return v;
+		}
 		u32x4 v;
 		v.x = ld(t); v.y = ld(t + 1); v.z = ld(t + 2); v.w = ld(t + 3);
 		return v;
@@ -212,18 +234,9 @@ template <int Q> struct InVec {
 template <int Q> struct OutRows { // the caller's message buffer, same row layout
 	uint8_t *p;
 	size_t stride;
-	int valid;
-	bool fast;
 	PDEV void st(u32 row, int q, u32 v) const
 	{
-		uint8_t *r = p + (size_t)row * stride + 4 * q;
-		if (fast) {
-			*reinterpret_cast<u32 *>(r) = v;
-			return;
-		}
-		for (int k = 0; k < 4; ++k)
-			if (4 * q + k < valid)
-				r[k] = (uint8_t)(v >> (8 * k));
+		*reinterpret_cast<u32 *>(p + (size_t)row * stride + 4 * q) = v;
 	}
 };
 
@@ -336,6 +349,125 @@ struct Group {
 				pass<KIND>(in, d, n, hgs, hgz, hrd);
 			else
 				pass<KIND>(GVec{sg + 2 * n}, d, n, hgs, hgz, hrd);
+		}
+	}
+
+
+	// ---- fused descent: polar_decoder.hh:28-51 applied D levels deep in one pass ----
+	// Source = level lvl (2^D * nd dwords, nd = Q << (lvl - D)); the lane that owns final index t
+	// loads the 2^D source words t + j*nd, folds them stage by stage in registers and stores the
+	// level lvl-k words t + j*nd, j < 2^(D-k), after stage k: every level is written once and
+	// the re-read by the next `left` of the unfused program never happens.
+	template <class H>
+	PDEV u32 madd_at(const H *hs, const H *hz, u32 eb, int t, u32 x, u32 y) const
+	{
+		u32 e = eb + (u32)(t / Q);
+		int i = pidx(e, t % Q), sh = (int)(e & 7);
+		return madd4(hs[i] << sh, hz[i] << sh, x, y);
+	}
+	template <class H>
+	PDEV u32x4 madd_at(const H *hs, const H *hz, u32 eb, int t, u32x4 x, u32x4 y) const
+	{
+		u32x4 r;
+		r.x = madd_at(hs, hz, eb, t, x.x, y.x);
+		r.y = madd_at(hs, hz, eb, t + 1, x.y, y.y);
+		r.z = madd_at(hs, hz, eb, t + 2, x.z, y.z);
+		r.w = madd_at(hs, hz, eb, t + 3, x.w, y.w);
+		return r;
+	}
+	static PDEV u32 ldE(const LVec &v, int t, u32) { return v.ld(t); }
+	static PDEV u32x4 ldE(const LVec &v, int t, u32x4) { return v.ld4(t); }
+	static PDEV u32 ldE(const GVec &v, int t, u32) { return v.ld(t); }
+	static PDEV u32x4 ldE(const GVec &v, int t, u32x4) { return v.ld4(t); }
+	static PDEV u32 ldE(const InVec<Q> &v, int t, u32) { return v.ld(t); }
+	static PDEV u32x4 ldE(const InVec<Q> &v, int t, u32x4) { return v.ld4(t); }
+	PDEV void stE(int level, int t, u32 v) const
+	{
+		if (level > RL)
+			sg[(Q << level) + t] = v;
+		else
+			sl[(Q << level) + t] = v;
+	}
+	PDEV void stE(int level, int t, u32x4 v) const
+	{
+		if (level > RL)
+			GVec{sg + (Q << level)}.st4(t, v);
+		else
+			LVec{sl + (Q << level)}.st4(t, v);
+	}
+	template <int D, class E, class A, class H>
+	PDEV void chain_lane(const A &a, int lvl, u32 pad, const H *hs, const H *hz, u32 eb, int t, int nd)
+	{
+		E x[1 << D];
+#pragma unroll
+		for (int j = 0; j < (1 << D); ++j)
+			x[j] = ldE(a, t + j * nd, E());
+#pragma unroll
+		for (int k = 1; k <= D; ++k) {
+			const int half = 1 << (D - k);
+			int kind = chain_kind(pad, k);
+			if (kind == 0) {
+#pragma unroll
+				for (int j = 0; j < half; ++j)
+					x[j] = prod4(x[j], x[j + half]);
+			} else if (kind == 2) {
+#pragma unroll
+				for (int j = 0; j < half; ++j)
+					x[j] = qadd4(x[j], x[j + half]);
+			} else {
+#pragma unroll
+				for (int j = 0; j < half; ++j)
+					x[j] = madd_at(hs, hz, eb, t + j * nd, x[j], x[j + half]);
+			}
+			if (!chain_skip(pad, k)) {
+#pragma unroll
+				for (int j = 0; j < half; ++j)
+					stE(lvl - k, t + j * nd, x[j]);
+			}
+		}
+	}
+	template <int D, class A, class H>
+	PDEV void chain_run(const A &a, int lvl, u32 pad, const H *hs, const H *hz, u32 eb)
+	{
+		int nd = Q << (lvl - D);
+		if (nd >= 256) {
+			PFOR_LANES(lane) {
+				for (int t = lane * 4; t < nd; t += 256)
+					chain_lane<D, u32x4>(a, lvl, pad, hs, hz, eb, t, nd);
+			}
+		} else {
+			PFOR_LANES(lane) {
+				for (int t = lane; t < nd; t += 64)
+					chain_lane<D, u32>(a, lvl, pad, hs, hz, eb, t, nd);
+			}
+		}
+		wave_sync();
+	}
+	template <int D>
+	PDEV void chain_at(int lvl, u32 hrd, u32 pad)
+	{
+		// the decided left child of a leading `right` is a level lvl-1 node
+		if (lvl - 1 <= RL) {
+			u32 eb = hrd & (u32)(W - 1);
+			if (lvl == top)
+				chain_run<D>(in, lvl, pad, hls, hlz, eb);
+			else if (lvl > RL)
+				chain_run<D>(GVec{sg + (Q << lvl)}, lvl, pad, hls, hlz, eb);
+			else
+				chain_run<D>(LVec{sl + (Q << lvl)}, lvl, pad, hls, hlz, eb);
+		} else {
+			if (lvl == top)
+				chain_run<D>(in, lvl, pad, hgs, hgz, hrd);
+			else
+				chain_run<D>(GVec{sg + (Q << lvl)}, lvl, pad, hgs, hgz, hrd);
+		}
+	}
+	PDEV void chain(int lvl, u32 hrd, u32 pad)
+	{
+		switch (chain_depth(pad)) {
+		case 1: chain_at<1>(lvl, hrd, pad); break;
+		case 2: chain_at<2>(lvl, hrd, pad); break;
+		default: chain_at<3>(lvl, hrd, pad); break;
 		}
 	}
 
@@ -719,7 +851,7 @@ struct Group {
 		d.op_level = prog[pc].op_level;
 		d.hrd = prog[pc].hrd;
 		d.row = prog[pc].row;
-		d.pad = 0;
+		d.pad = prog[pc].pad;
 		return d;
 	}
 
@@ -729,12 +861,13 @@ struct Group {
 	{
 		DevOp cur = fetch(prog, 0);
 		for (int pc = 1;; ++pc) {
-			u32 op = cur.op_level & 255, hrd = cur.hrd, row = cur.row;
+			u32 op = cur.op_level & 255, hrd = cur.hrd, row = cur.row, pad = cur.pad;
 			int lvl = (int)(cur.op_level >> 8);
 			if (op == OP_END)
 				break;
 			cur = fetch(prog, pc); // fetched while the current node runs
 			switch (op) {
+			case OP_CHAIN: chain(lvl, hrd, pad); break;
 			case OP_LEFT: soft_pass<0>(lvl, hrd); break;
 			case OP_RIGHT: soft_pass<1>(lvl, hrd); break;
 			case OP_RATE0_RIGHT: soft_pass<2>(lvl, hrd); break;

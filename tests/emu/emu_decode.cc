@@ -61,9 +61,14 @@ template <int Q, int RL>
 static int run(int8_t *msg, const int8_t *cw, const HostProgram &hp, size_t frames)
 {
 	typedef Group<Q, RL> G;
-	const int FR = 4 * Q;
+	const size_t FR = 4 * Q, n = (size_t)1 << hp.top;
+	// ragged batches go through a padded copy, exactly as the host wrapper of the library does
+	size_t fp = (frames + FR - 1) / FR * FR;
+	std::vector<int8_t> pin(n * fp, 0), pout((size_t)(hp.rows ? hp.rows : 1) * fp, 0);
+	for (size_t i = 0; i < n; ++i)
+		memcpy(&pin[i * fp], cw + i * frames, frames);
 	std::vector<u32> lds(G::LDS_DWORDS), soft((size_t)Q << hp.top), planes(((size_t)Q << hp.top) / 8 * 2 + 2);
-	for (size_t g0 = 0; g0 < frames; g0 += FR) {
+	for (size_t g0 = 0; g0 < fp; g0 += FR) {
 		// poison everything a fresh wave would find uninitialised
 		for (auto &v : lds) v = 0xDEADBEEF;
 		for (auto &v : soft) v = 0xDEADBEEF;
@@ -77,19 +82,19 @@ static int run(int8_t *msg, const int8_t *cw, const HostProgram &hp, size_t fram
 		g.hgs = planes.data();
 		g.hgz = planes.data() + planes.size() / 2;
 		g.top = hp.top;
-		int valid = (int)(frames - g0 < (size_t)FR ? frames - g0 : FR);
-		bool fast = valid == FR && frames % 4 == 0;
-		g.in = InVec<Q>{(const uint8_t *)cw + g0, frames, valid, fast};
-		g.out = OutRows<Q>{(uint8_t *)msg + g0, frames, valid, fast};
+		g.in = InVec<Q>{(const uint8_t *)pin.data() + g0, fp};
+		g.out = OutRows<Q>{(uint8_t *)pout.data() + g0, fp};
 		g.run(hp.ops.data());
 	}
+	for (size_t r = 0; r < hp.rows; ++r)
+		memcpy(msg + r * frames, &pout[r * fp], frames);
 	return 0;
 }
 
 extern "C" int emu_decode(int8_t *msg, const int8_t *cw, const uint8_t *prog, int len, size_t frames, int Q, int RL)
 {
 	HostProgram hp;
-	int err = translate_program(prog, len, hp);
+	int err = translate_program(prog, len, hp, Q);
 	if (err)
 		return -err;
 #define CASE(q, r) if (Q == q && RL == r) return run<q, r>(msg, cw, hp, frames) ? -100 : (int)hp.rows;
