@@ -2,7 +2,8 @@
 import ctypes
 import os
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpolar_hip.so")
+# POLAR_HIP_LIB: diagnostic builds of the same library (tools/), e.g. libpolar_hip_prof.so
+LIB_PATH = os.environ.get("POLAR_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpolar_hip.so")
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int

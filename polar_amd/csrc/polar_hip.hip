@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -50,13 +51,15 @@ struct DecodeArgs {
 	size_t stride;         // bytes per row of cw and msg: a multiple of 4, groups * 4Q <= stride
 	u32 groups;
 	int top;
+	u32 stagger_ticks;     // start of block b is delayed by frac(b * phi) * stagger_ticks (100 MHz ticks)
+	unsigned long long *prof; // diagnostic build (POLAR_PROFILE) only
 };
 
 // Persistent wavefronts: block b walks the groups b, b + gridDim, ... Blocks are dealt to
 // the 8 XCDs round-robin, so within one sweep the blocks that share an XCD (equal b % 8) take
 // neighbouring groups: those groups share the 128-byte lines of every input row.
 template <int Q, int RL>
-__global__ void __launch_bounds__(64) sc_decode_kernel(DecodeArgs a)
+__global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
 {
 	typedef Group<Q, RL> G;
 	__shared__ __attribute__((aligned(16))) u32 lds[G::LDS_DWORDS];
@@ -73,6 +76,17 @@ __global__ void __launch_bounds__(64) sc_decode_kernel(DecodeArgs a)
 	g.hgs = arena ? arena + ((size_t)Q << a.top) : nullptr;
 	g.hgz = arena ? g.hgs + plane : nullptr;
 	g.top = a.top;
+#ifdef POLAR_PROFILE
+	g.prof = a.prof;
+#endif
+	if (a.stagger_ticks) {
+		// Wavefronts that start together stay in step through the whole program and hit its
+		// HBM-heavy upper levels all at once; spreading the starts over one pass evens that out.
+		unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+		unsigned long long wait = ((unsigned long long)((b * 2654435769u) >> 8) * a.stagger_ticks) >> 24;
+		while (__builtin_amdgcn_s_memrealtime() - t0 < wait)
+			__builtin_amdgcn_s_sleep(64);
+	}
 	for (u32 base = 0; base < a.groups; base += nb) {
 		u32 grp = base + slot;
 		if (grp >= a.groups)
@@ -94,12 +108,14 @@ struct KernelVariant {
 
 #define VARIANT(q, rl) {q, rl, sc_decode_kernel<q, rl>, sizeof(u32) * (size_t)Group<q, rl>::LDS_DWORDS}
 static const KernelVariant g_variants[] = {
-	// ~20 KB of LDS per wavefront (7-8 wavefronts per CU)
+	// 256 frames per wavefront: every node keeps all 64 lanes busy
+	VARIANT(64, 4), VARIANT(64, 5), VARIANT(64, 6), VARIANT(32, 5), VARIANT(32, 6), VARIANT(32, 7),
+	// ~10 KB of LDS per wavefront (15 wavefronts per CU)
+	VARIANT(16, 6), VARIANT(8, 7),
+	// ~20 KB (7 per CU)
 	VARIANT(1, 11), VARIANT(2, 10), VARIANT(4, 9), VARIANT(8, 8), VARIANT(16, 7),
-	// ~40 KB (3-4 per CU)
-	VARIANT(1, 12), VARIANT(2, 11), VARIANT(4, 10), VARIANT(8, 9), VARIANT(16, 8),
-	// ~10 KB (15-16 per CU)
-	VARIANT(2, 9), VARIANT(4, 8), VARIANT(8, 7), VARIANT(16, 6),
+	// ~40 KB (3 per CU)
+	VARIANT(4, 10), VARIANT(4, 8),
 };
 #undef VARIANT
 
@@ -447,7 +463,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	if (!groups)
 		return POLAR_OK;
 	const size_t padded = groups * fpw;
-	const bool direct = padded == frames && (uintptr_t)codeword % 4 == 0 && (uintptr_t)message % 4 == 0;
+	const bool direct = padded == frames && (uintptr_t)codeword % 16 == 0 && (uintptr_t)message % 16 == 0;
 	const uint8_t *cw = (const uint8_t *)codeword;
 	uint8_t *msg = (uint8_t *)message;
 	int rc;
@@ -466,10 +482,13 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	size_t blocks = (size_t)per_cu * h->cus;
 	if (h->cfg_max_waves && (size_t)h->cfg_max_waves < blocks)
 		blocks = h->cfg_max_waves;
-	if (groups < blocks)
-		blocks = groups;
-	if (blocks >= 8)
-		blocks -= blocks % 8;
+	// every wavefront walks the same number of groups: no idle tail behind a last partial sweep
+	size_t sweeps = (groups + blocks - 1) / blocks;
+	blocks = (groups + sweeps - 1) / sweeps;
+	if (blocks >= 8 && blocks % 8)
+		blocks += 8 - blocks % 8; // multiple of 8 for the XCD-aware group order
+	if (getenv("POLAR_HIP_DEBUG"))
+		fprintf(stderr, "polar_hip: decode Q=%d RL=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d\n", v->q, v->rl, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct);
 	DecodeArgs a;
 	a.prog = lp.dev[v->q];
 	a.cw = cw;
@@ -479,6 +498,9 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	a.top = lp.host.top;
 	a.scratch = nullptr;
 	a.block_dwords = 0;
+	a.stagger_ticks = 0;
+	if (const char *e = getenv("POLAR_HIP_STAGGER_US"))
+		a.stagger_ticks = (u32)(atof(e) * 100.0);
 	if (lp.host.top > v->rl) {
 		size_t soft = (size_t)v->q << lp.host.top;
 		a.block_dwords = soft + 2 * (soft / 8);
@@ -486,10 +508,35 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 			return rc;
 		a.scratch = (u32 *)h->scratch.p;
 	}
+	a.prof = nullptr;
+#ifdef POLAR_PROFILE
+	static unsigned long long *prof_dev = nullptr;
+	if (!prof_dev)
+		HIP_TRY(hipMalloc((void **)&prof_dev, 16 * 32 * 2 * 8));
+	HIP_TRY(hipMemsetAsync(prof_dev, 0, 16 * 32 * 2 * 8, stream));
+	a.prof = prof_dev;
+#endif
 	if (timed)
 		HIP_TRY(hipEventRecord(h->ev0, stream));
 	hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64), 0, stream, a);
 	HIP_TRY(hipGetLastError());
+#ifdef POLAR_PROFILE
+	{
+		static unsigned long long host[16 * 32 * 2];
+		HIP_TRY(hipMemcpyAsync(host, prof_dev, sizeof(host), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+		static const char *names[16] = {"left", "right", "comb", "rate0", "rate1", "rep", "spc", "r0right", "r0comb", "r1comb", "?", "chain1", "chain2", "chain3", "?", "?"};
+		unsigned long long total = 0;
+		for (int i = 0; i < 16 * 32; ++i)
+			total += host[2 * i];
+		fprintf(stderr, "polar_hip profile: wave-cycles per node kind and level (blocks=%zu, total %.3e cycles = %.1f Mcycles per wave)\n", blocks, (double)total, total / 1e6 / blocks);
+		for (int k = 0; k < 16; ++k)
+			for (int l = 0; l < 32; ++l)
+				if (host[2 * (k * 32 + l) + 1])
+					fprintf(stderr, "  %-8s L%-2d calls/wave %8.1f  cycles/call %9.0f  share %5.2f%%\n", names[k], l, (double)host[2 * (k * 32 + l) + 1] / blocks,
+						(double)host[2 * (k * 32 + l)] / host[2 * (k * 32 + l) + 1], 100.0 * host[2 * (k * 32 + l)] / total);
+	}
+#endif
 	if (timed) {
 		HIP_TRY(hipEventRecord(h->ev1, stream));
 		h->timed = true;

@@ -218,12 +218,9 @@ template <int Q> struct InVec {
 	}
 	PDEV u32x4 ld4(int t) const
 	{
-		if (Q % 4 == 0) { // four consecutive quads of one row
+		if (Q % 4 == 0) { // four consecutive quads of one row: rows are 16-byte aligned then
 			int i = t / Q, q = t % Q;
-			const u32 *r = reinterpret_cast<const u32 *>(p + (size_t)i * stride + 4 * q);
-			u32x4 v;
-			v.x = r[0]; v.y = r[1]; v.z = r[2]; v.w = r[3];
-			return v;
+			return *reinterpret_cast<const u32x4 *>(p + (size_t)i * stride + 4 * q);
 		}
 		u32x4 v;
 		v.x = ld(t); v.y = ld(t + 1); v.z = ld(t + 2); v.w = ld(t + 3);
@@ -238,7 +235,14 @@ template <int Q> struct OutRows { // the caller's message buffer, same row layou
 	{
 		*reinterpret_cast<u32 *>(p + (size_t)row * stride + 4 * q) = v;
 	}
+	PDEV void st4(u32 row, int q, u32x4 v) const // q % 4 == 0, Q % 4 == 0
+	{
+		*reinterpret_cast<u32x4 *>(p + (size_t)row * stride + 4 * q) = v;
+	}
 };
+
+template <class A> struct SrcIsLds { static const bool value = false; };
+template <> struct SrcIsLds<LVec> { static const bool value = true; };
 
 template <class T> struct Planes { // partial-sum bit planes of one node
 	T *s, *z;
@@ -285,6 +289,9 @@ struct Group {
 	InVec<Q> in;
 	OutRows<Q> out;
 	int top;
+#ifdef POLAR_PROFILE
+	unsigned long long *prof; // [16 node kinds][32 levels][cycles, calls], diagnostic build only
+#endif
 
 	// plane dword of element e for frame quad q
 	static PDEV int pidx(u32 e, int q) { return (int)(e >> 3) * Q + q; }
@@ -395,34 +402,42 @@ struct Group {
 		else
 			LVec{sl + (Q << level)}.st4(t, v);
 	}
-	template <int D, class E, class A, class H>
-	PDEV void chain_lane(const A &a, int lvl, u32 pad, const H *hs, const H *hz, u32 eb, int t, int nd)
+	// U independent final indices t, t + step, ... per lane: all 2^D * U loads are issued before
+	// the first use, which is what keeps enough bytes in flight for the HBM-resident levels
+	template <int D, class E, int U, class A, class H>
+	PDEV void chain_lane(const A &a, int lvl, u32 pad, const H *hs, const H *hz, u32 eb, int t, int nd, int step)
 	{
-		E x[1 << D];
+		E x[U][1 << D];
 #pragma unroll
-		for (int j = 0; j < (1 << D); ++j)
-			x[j] = ldE(a, t + j * nd, E());
+		for (int u = 0; u < U; ++u)
 #pragma unroll
-		for (int k = 1; k <= D; ++k) {
-			const int half = 1 << (D - k);
-			int kind = chain_kind(pad, k);
-			if (kind == 0) {
+			for (int j = 0; j < (1 << D); ++j)
+				x[u][j] = ldE(a, t + u * step + j * nd, E());
 #pragma unroll
-				for (int j = 0; j < half; ++j)
-					x[j] = prod4(x[j], x[j + half]);
-			} else if (kind == 2) {
+		for (int u = 0; u < U; ++u) {
+			const int tu = t + u * step;
 #pragma unroll
-				for (int j = 0; j < half; ++j)
-					x[j] = qadd4(x[j], x[j + half]);
-			} else {
+			for (int k = 1; k <= D; ++k) {
+				const int half = 1 << (D - k);
+				int kind = chain_kind(pad, k);
+				if (kind == 0) {
 #pragma unroll
-				for (int j = 0; j < half; ++j)
-					x[j] = madd_at(hs, hz, eb, t + j * nd, x[j], x[j + half]);
-			}
-			if (!chain_skip(pad, k)) {
+					for (int j = 0; j < half; ++j)
+						x[u][j] = prod4(x[u][j], x[u][j + half]);
+				} else if (kind == 2) {
 #pragma unroll
-				for (int j = 0; j < half; ++j)
-					stE(lvl - k, t + j * nd, x[j]);
+					for (int j = 0; j < half; ++j)
+						x[u][j] = qadd4(x[u][j], x[u][j + half]);
+				} else {
+#pragma unroll
+					for (int j = 0; j < half; ++j)
+						x[u][j] = madd_at(hs, hz, eb, tu + j * nd, x[u][j], x[u][j + half]);
+				}
+				if (!chain_skip(pad, k)) {
+#pragma unroll
+					for (int j = 0; j < half; ++j)
+						stE(lvl - k, tu + j * nd, x[u][j]);
+				}
 			}
 		}
 	}
@@ -430,15 +445,22 @@ struct Group {
 	PDEV void chain_run(const A &a, int lvl, u32 pad, const H *hs, const H *hz, u32 eb)
 	{
 		int nd = Q << (lvl - D);
-		if (nd >= 256) {
+		// loads in flight per lane from HBM: 16 x 16 bytes
+		const int U = (SrcIsLds<A>::value || D > 3) ? 1 : (16 >> D);
+		if (U > 1 && nd >= 256 * U) {
+			PFOR_LANES(lane) {
+				for (int t = lane * 4; t < nd; t += 256 * U)
+					chain_lane<D, u32x4, U>(a, lvl, pad, hs, hz, eb, t, nd, 256);
+			}
+		} else if (nd >= 256) {
 			PFOR_LANES(lane) {
 				for (int t = lane * 4; t < nd; t += 256)
-					chain_lane<D, u32x4>(a, lvl, pad, hs, hz, eb, t, nd);
+					chain_lane<D, u32x4, 1>(a, lvl, pad, hs, hz, eb, t, nd, 0);
 			}
 		} else {
 			PFOR_LANES(lane) {
 				for (int t = lane; t < nd; t += 64)
-					chain_lane<D, u32>(a, lvl, pad, hs, hz, eb, t, nd);
+					chain_lane<D, u32, 1>(a, lvl, pad, hs, hz, eb, t, nd, 0);
 			}
 		}
 		wave_sync();
@@ -636,11 +658,26 @@ struct Group {
 			wave_sync();
 		}
 		int cnt = (len - first) * Q;
-		PFOR_LANES(lane) {
-			for (int t = lane; t < cnt; t += 64) {
-				int e = first + t / Q, q = t % Q;
-				int i = pidx((u32)e, q), sh = e & 7;
-				out.st(row + (u32)(e - first), q, symbols(ts[i] << sh, tz[i] << sh));
+		if (Q % 4 == 0) {
+			PFOR_LANES(lane) {
+				for (int t = lane * 4; t < cnt; t += 256) {
+					int e = first + t / Q, q = t % Q;
+					int i = pidx((u32)e, q), sh = e & 7;
+					u32x4 v;
+					v.x = symbols(ts[i] << sh, tz[i] << sh);
+					v.y = symbols(ts[i + 1] << sh, tz[i + 1] << sh);
+					v.z = symbols(ts[i + 2] << sh, tz[i + 2] << sh);
+					v.w = symbols(ts[i + 3] << sh, tz[i + 3] << sh);
+					out.st4(row + (u32)(e - first), q, v);
+				}
+			}
+		} else {
+			PFOR_LANES(lane) {
+				for (int t = lane; t < cnt; t += 64) {
+					int e = first + t / Q, q = t % Q;
+					int i = pidx((u32)e, q), sh = e & 7;
+					out.st(row + (u32)(e - first), q, symbols(ts[i] << sh, tz[i] << sh));
+				}
 			}
 		}
 		wave_sync();
@@ -844,6 +881,20 @@ struct Group {
 		}
 	}
 
+	PDEV void node(u32 op, int lvl, u32 hrd, u32 row, u32 pad)
+	{
+		switch (op) {
+		case OP_CHAIN: chain(lvl, hrd, pad); break;
+		case OP_LEFT: soft_pass<0>(lvl, hrd); break;
+		case OP_RIGHT: soft_pass<1>(lvl, hrd); break;
+		case OP_RATE0_RIGHT: soft_pass<2>(lvl, hrd); break;
+		case OP_COMB: comb_any<false>(lvl, hrd); break;
+		case OP_RATE0_COMB: comb_any<true>(lvl, hrd); break;
+		case OP_RATE1_COMB: rate1_comb_any(lvl, hrd, row); break;
+		default: leaf(op, lvl, hrd, row); break;
+		}
+	}
+
 	template <class P>
 	static PDEV DevOp fetch(P prog, int pc)
 	{
@@ -866,16 +917,20 @@ struct Group {
 			if (op == OP_END)
 				break;
 			cur = fetch(prog, pc); // fetched while the current node runs
-			switch (op) {
-			case OP_CHAIN: chain(lvl, hrd, pad); break;
-			case OP_LEFT: soft_pass<0>(lvl, hrd); break;
-			case OP_RIGHT: soft_pass<1>(lvl, hrd); break;
-			case OP_RATE0_RIGHT: soft_pass<2>(lvl, hrd); break;
-			case OP_COMB: comb_any<false>(lvl, hrd); break;
-			case OP_RATE0_COMB: comb_any<true>(lvl, hrd); break;
-			case OP_RATE1_COMB: rate1_comb_any(lvl, hrd, row); break;
-			default: leaf(op, lvl, hrd, row); break;
+#ifdef POLAR_PROFILE
+			unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+			node(op, lvl, hrd, row, pad);
+			__builtin_amdgcn_s_waitcnt(0);
+			unsigned long long dt_ = __builtin_amdgcn_s_memtime() - t0_;
+			if (prof && (threadIdx.x & 63) == 0) {
+				u32 slot = ((op == OP_CHAIN ? 10 + chain_depth(pad) : op) * 32 + (u32)lvl) * 2;
+				atomicAdd(&prof[slot], dt_);
+				atomicAdd(&prof[slot + 1], 1ull);
 			}
+#else
+			node(op, lvl, hrd, row, pad);
+#endif
+
 		}
 	}
 };

@@ -19,6 +19,7 @@ typedef uint32_t u32;
 struct alignas(16) u32x4 { u32 x, y, z, w; };
 typedef u32 lds_u32;
 typedef u32x4 lds_u32x4;
+
 static inline int16_t sat16(int v) { return (int16_t)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
 #define EMU_PK(name, expr) \
 	static inline u32 name(u32 a, u32 b) \
