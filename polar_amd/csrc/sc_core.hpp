@@ -241,6 +241,14 @@ template <int Q> struct OutRows { // the caller's message buffer, same row layou
 	}
 };
 
+// 16-byte accesses through typed pointers (plane arrays, scratch regions): 16-byte aligned
+PDEV u32x4 ldp4(const u32 *p) { return *reinterpret_cast<const u32x4 *>(p); }
+PDEV void stp4(u32 *p, u32x4 v) { *reinterpret_cast<u32x4 *>(p) = v; }
+#ifndef POLAR_EMU
+PDEV u32x4 ldp4(const lds_u32 *p) { return *reinterpret_cast<const lds_u32x4 *>(p); }
+PDEV void stp4(lds_u32 *p, u32x4 v) { *reinterpret_cast<lds_u32x4 *>(p) = v; }
+#endif
+
 template <class A> struct SrcIsLds { static const bool value = false; };
 template <> struct SrcIsLds<LVec> { static const bool value = true; };
 
@@ -317,6 +325,7 @@ struct Group {
 		const Group *g;
 		const u32 *base; // null: the caller's input
 		PDEV u32 ld(int t) const { return base ? base[t] : g->in.ld(t); }
+		PDEV u32x4 ld4(int t) const { return base ? ldp4(base + t) : g->in.ld4(t); }
 	};
 	PDEV AnySrc any_src(int lvl) const { return AnySrc{this, lvl == top ? nullptr : fregion(lvl)}; }
 
@@ -388,6 +397,7 @@ struct Group {
 	static PDEV u32x4 ldE(const GVec &v, int t, u32x4) { return v.ld4(t); }
 	static PDEV u32 ldE(const InVec<Q> &v, int t, u32) { return v.ld(t); }
 	static PDEV u32x4 ldE(const InVec<Q> &v, int t, u32x4) { return v.ld4(t); }
+	static PDEV u32x4 ldE(const AnySrc &v, int t, u32x4) { return v.ld4(t); }
 	PDEV void stE(int level, int t, u32 v) const
 	{
 		if (level > RL)
@@ -520,19 +530,52 @@ struct Group {
 		} else {
 			int n = (h >> 3) * Q; // plane dwords per half
 			int il0 = pidx(c.eb, 0), ir0 = pidx(c.eb + h, 0), ol0 = pidx(o.eb, 0), or0 = pidx(o.eb + h, 0);
-			PFOR_LANES(lane) {
-				for (int t = lane; t < n; t += 64) {
-					u32 rs = c.s[ir0 + t], rz = c.z[ir0 + t];
-					if (RATE0) {
-						o.s[ol0 + t] = rs;
-						o.z[ol0 + t] = rz;
-					} else {
-						o.s[ol0 + t] = c.s[il0 + t] ^ rs;
-						o.z[ol0 + t] = c.z[il0 + t] | rz;
+			if (n >= 256) { // 16-byte accesses, U of them in flight per array and lane
+				const int U = 4;
+				PFOR_LANES(lane) {
+					for (int t0 = lane * 4; t0 < n; t0 += 256 * U) {
+						u32x4 ls[U], lz[U], rs[U], rz[U];
+#pragma unroll
+						for (int u = 0; u < U; ++u) {
+							int t = t0 + 256 * u;
+							if (t < n) {
+								rs[u] = ldp4(c.s + ir0 + t);
+								rz[u] = ldp4(c.z + ir0 + t);
+								if (!RATE0) {
+									ls[u] = ldp4(c.s + il0 + t);
+									lz[u] = ldp4(c.z + il0 + t);
+								}
+							}
+						}
+#pragma unroll
+						for (int u = 0; u < U; ++u) {
+							int t = t0 + 256 * u;
+							if (t < n) {
+								stp4(o.s + ol0 + t, RATE0 ? rs[u] : ls[u] ^ rs[u]);
+								stp4(o.z + ol0 + t, RATE0 ? rz[u] : lz[u] | rz[u]);
+								if (!inplace) {
+									stp4(o.s + or0 + t, rs[u]);
+									stp4(o.z + or0 + t, rz[u]);
+								}
+							}
+						}
 					}
-					if (!inplace) {
-						o.s[or0 + t] = rs;
-						o.z[or0 + t] = rz;
+				}
+			} else {
+				PFOR_LANES(lane) {
+					for (int t = lane; t < n; t += 64) {
+						u32 rs = c.s[ir0 + t], rz = c.z[ir0 + t];
+						if (RATE0) {
+							o.s[ol0 + t] = rs;
+							o.z[ol0 + t] = rz;
+						} else {
+							o.s[ol0 + t] = c.s[il0 + t] ^ rs;
+							o.z[ol0 + t] = c.z[il0 + t] | rz;
+						}
+						if (!inplace) {
+							o.s[or0 + t] = rs;
+							o.z[or0 + t] = rz;
+						}
 					}
 				}
 			}
@@ -647,12 +690,26 @@ struct Group {
 		int noct = len >> 3;
 		int n = noct * Q;
 		for (int ho = 1; ho < noct; ho *= 2) { // stages h = 8*ho
-			PFOR_LANES(lane) {
-				for (int t = lane; t < n / 2; t += 64) {
-					int o = t / Q, q = t % Q;
-					int lo = ((o / ho) * 2 * ho + (o % ho)) * Q + q, hi = lo + ho * Q;
-					ts[lo] ^= ts[hi];
-					tz[lo] |= tz[hi];
+			if (Q % 4 == 0 && n >= 512) {
+				PFOR_LANES(lane) {
+					for (int t = lane * 4; t < n / 2; t += 256) {
+						int o = t / Q, q = t % Q;
+						int lo = ((o / ho) * 2 * ho + (o % ho)) * Q + q, hi = lo + ho * Q;
+						u32x4 a = ldp4(ts + lo), b = ldp4(ts + hi), c = ldp4(tz + lo), d = ldp4(tz + hi);
+						a.x ^= b.x; a.y ^= b.y; a.z ^= b.z; a.w ^= b.w;
+						c.x |= d.x; c.y |= d.y; c.z |= d.z; c.w |= d.w;
+						stp4(ts + lo, a);
+						stp4(tz + lo, c);
+					}
+				}
+			} else {
+				PFOR_LANES(lane) {
+					for (int t = lane; t < n / 2; t += 64) {
+						int o = t / Q, q = t % Q;
+						int lo = ((o / ho) * 2 * ho + (o % ho)) * Q + q, hi = lo + ho * Q;
+						ts[lo] ^= ts[hi];
+						tz[lo] |= tz[hi];
+					}
 				}
 			}
 			wave_sync();
@@ -663,11 +720,11 @@ struct Group {
 				for (int t = lane * 4; t < cnt; t += 256) {
 					int e = first + t / Q, q = t % Q;
 					int i = pidx((u32)e, q), sh = e & 7;
-					u32x4 v;
-					v.x = symbols(ts[i] << sh, tz[i] << sh);
-					v.y = symbols(ts[i + 1] << sh, tz[i + 1] << sh);
-					v.z = symbols(ts[i + 2] << sh, tz[i + 2] << sh);
-					v.w = symbols(ts[i + 3] << sh, tz[i + 3] << sh);
+					u32x4 a = ldp4(ts + i), b = ldp4(tz + i), v;
+					v.x = symbols(a.x << sh, b.x << sh);
+					v.y = symbols(a.y << sh, b.y << sh);
+					v.z = symbols(a.z << sh, b.z << sh);
+					v.w = symbols(a.w << sh, b.w << sh);
 					out.st4(row + (u32)(e - first), q, v);
 				}
 			}
@@ -739,6 +796,10 @@ struct Group {
 			return;
 		}
 		// spc (polar_decoder.hh:107-127)
+		if (WIDE_LEAVES && n >= 256) {
+			spc_wide(lvl, src, p, tmp, sl + Q, row);
+			return;
+		}
 		PFOR_LANES(lane) {
 			for (int t = lane; t < n; t += 64) {
 				int o = t / Q, q = t % Q;
@@ -789,6 +850,112 @@ struct Group {
 				trans_octet(s, z, 8);
 				ts[t] = s;
 				tz[t] = 0;
+			}
+		}
+		wave_sync();
+		trans_emit(ts, tz, len, 1, row);
+	}
+
+	// spc (polar_decoder.hh:107-127) for nodes of >= 256 plane dwords: every lane owns four frame
+	// quads of every (256/Q)-th octet, keeps the running weakest magnitude and parity in registers
+	// and has its eight 16-byte loads in flight together. red: 768 dwords of LDS.
+	static const bool WIDE_LEAVES = Q % 4 == 0 && LDS_SOFT >= Q + 768;
+	template <class SRC, class T>
+	PDEV void spc_wide(int lvl, const SRC &src, Planes<T> p, T *tmp, lds_u32 *red, u32 row)
+	{
+		int len = 1 << lvl, n = (len >> 3) * Q;
+		int i0 = pidx(p.eb, 0);
+		T *ts = tmp, *tz = tmp + n;
+		PFOR_LANES(lane) {
+			u32 amh[4], aml[4], apx[4];
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				amh[c] = aml[c] = 0x7F007F00u;
+				apx[c] = 0;
+			}
+			for (int t = lane * 4; t < n; t += 256) {
+				int o = t / Q, q = t % Q;
+				u32x4 x[8];
+#pragma unroll
+				for (int j = 0; j < 8; ++j)
+					x[j] = ldE(src, (8 * o + j) * Q + q, u32x4());
+				u32 sg4[4] = {0, 0, 0, 0};
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					u32 xc[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+#pragma unroll
+					for (int c = 0; c < 4; ++c) {
+						sg4[c] |= (xc[c] & SIGN_BITS) >> j;
+						amh[c] = pk_min(amh[c], abs_half(split_hi(xc[c])));
+						aml[c] = pk_min(aml[c], abs_half(split_lo(xc[c])));
+					}
+				}
+				u32x4 sv;
+				sv.x = sg4[0]; sv.y = sg4[1]; sv.z = sg4[2]; sv.w = sg4[3];
+				stp4(ts + t, sv);
+#pragma unroll
+				for (int c = 0; c < 4; ++c)
+					apx[c] ^= sg4[c];
+			}
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				red[lane * 4 + c] = amh[c];
+				red[256 + lane * 4 + c] = aml[c];
+				red[512 + lane * 4 + c] = apx[c];
+			}
+		}
+		wave_sync();
+		lds_u32 *wk = tl; // per quad: weakest magnitude (two arrays) and odd-parity mask
+		PFOR_LANES(lane) {
+			if (lane < Q) {
+				u32 mh = 0x7F007F00u, ml = 0x7F007F00u, px = 0;
+				for (int i = lane; i < 256; i += Q) { // entry i belongs to quad i % Q
+					mh = pk_min(mh, red[i]);
+					ml = pk_min(ml, red[256 + i]);
+					px ^= red[512 + i];
+				}
+				wk[lane] = mh;
+				wk[Q + lane] = ml;
+				wk[2 * Q + lane] = odd_mask(px);
+			}
+		}
+		wave_sync();
+		PFOR_LANES(lane) {
+			for (int t = lane * 4; t < n; t += 256) {
+				int o = t / Q, q = t % Q;
+				u32x4 whv = ldp4(wk + q), wlv = ldp4(wk + Q + q), odv = ldp4(wk + 2 * Q + q), sv = ldp4(ts + t);
+				u32 wh[4] = {whv.x, whv.y, whv.z, whv.w}, wl[4] = {wlv.x, wlv.y, wlv.z, wlv.w};
+				u32 od[4] = {odv.x, odv.y, odv.z, odv.w}, sg4[4] = {sv.x, sv.y, sv.z, sv.w};
+				if (od[0] | od[1] | od[2] | od[3]) {
+					u32x4 x[8];
+#pragma unroll
+					for (int j = 0; j < 8; ++j)
+						x[j] = ldE(src, (8 * o + j) * Q + q, u32x4());
+					u32 tie[4] = {0, 0, 0, 0};
+#pragma unroll
+					for (int j = 0; j < 8; ++j) {
+						u32 xc[4] = {x[j].x, x[j].y, x[j].z, x[j].w};
+#pragma unroll
+						for (int c = 0; c < 4; ++c)
+							tie[c] |= tie_bits(xc[c], wh[c], wl[c]) >> j;
+					}
+#pragma unroll
+					for (int c = 0; c < 4; ++c)
+						sg4[c] ^= tie[c] & od[c];
+				}
+				u32x4 zero;
+				zero.x = zero.y = zero.z = zero.w = 0;
+				sv.x = sg4[0]; sv.y = sg4[1]; sv.z = sg4[2]; sv.w = sg4[3];
+				stp4(p.s + i0 + t, sv);
+				stp4(p.z + i0 + t, zero);
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					u32 z = 0;
+					trans_octet(sg4[c], z, 8);
+				}
+				sv.x = sg4[0]; sv.y = sg4[1]; sv.z = sg4[2]; sv.w = sg4[3];
+				stp4(ts + t, sv);
+				stp4(tz + t, zero);
 			}
 		}
 		wave_sync();

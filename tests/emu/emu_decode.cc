@@ -17,6 +17,9 @@
 namespace polar {
 typedef uint32_t u32;
 struct alignas(16) u32x4 { u32 x, y, z, w; };
+static inline u32x4 operator^(u32x4 a, u32x4 b) { return u32x4{a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w}; }
+static inline u32x4 operator|(u32x4 a, u32x4 b) { return u32x4{a.x | b.x, a.y | b.y, a.z | b.z, a.w | b.w}; }
+static inline u32x4 operator&(u32x4 a, u32x4 b) { return u32x4{a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w}; }
 typedef u32 lds_u32;
 typedef u32x4 lds_u32x4;
 
@@ -68,7 +71,11 @@ static int run(int8_t *msg, const int8_t *cw, const HostProgram &hp, size_t fram
 	std::vector<int8_t> pin(n * fp, 0), pout((size_t)(hp.rows ? hp.rows : 1) * fp, 0);
 	for (size_t i = 0; i < n; ++i)
 		memcpy(&pin[i * fp], cw + i * frames, frames);
-	std::vector<u32> lds(G::LDS_DWORDS), soft((size_t)Q << hp.top), planes(((size_t)Q << hp.top) / 8 * 2 + 2);
+	// same arena layout as the kernel (polar_hip.hip): soft, sign plane, zero plane; 16-byte aligned
+	const size_t nsoft = (size_t)Q << hp.top, nplane = nsoft / 8 + 1;
+	std::vector<u32x4> lds_((G::LDS_DWORDS + 3) / 4), soft_((nsoft + 3) / 4), planes_((2 * nplane + 3) / 4 + 1);
+	struct Span { u32 *p; size_t n; u32 *data() { return p; } u32 *begin() { return p; } u32 *end() { return p + n; } size_t size() const { return n; } };
+	Span lds{(u32 *)lds_.data(), (size_t)G::LDS_DWORDS}, soft{(u32 *)soft_.data(), nsoft}, planes{(u32 *)planes_.data(), 2 * nplane};
 	for (size_t g0 = 0; g0 < fp; g0 += FR) {
 		// poison everything a fresh wave would find uninitialised
 		for (auto &v : lds) v = 0xDEADBEEF;
@@ -81,7 +88,7 @@ static int run(int8_t *msg, const int8_t *cw, const HostProgram &hp, size_t fram
 		g.tl = g.hlz + G::LDS_PLANE;
 		g.sg = soft.data();
 		g.hgs = planes.data();
-		g.hgz = planes.data() + planes.size() / 2;
+		g.hgz = planes.data() + nsoft / 8;
 		g.top = hp.top;
 		g.in = InVec<Q>{(const uint8_t *)pin.data() + g0, fp};
 		g.out = OutRows<Q>{(uint8_t *)pout.data() + g0, fp};
@@ -99,7 +106,7 @@ extern "C" int emu_decode(int8_t *msg, const int8_t *cw, const uint8_t *prog, in
 	if (err)
 		return -err;
 #define CASE(q, r) if (Q == q && RL == r) return run<q, r>(msg, cw, hp, frames) ? -100 : (int)hp.rows;
-	CASE(1, 4) CASE(1, 6) CASE(2, 5) CASE(4, 4) CASE(4, 7) CASE(4, 9) CASE(8, 6) CASE(16, 7) CASE(16, 5)
+	CASE(1, 4) CASE(1, 6) CASE(2, 5) CASE(4, 4) CASE(4, 7) CASE(4, 9) CASE(8, 6) CASE(16, 7) CASE(16, 5) CASE(32, 5)
 #undef CASE
 	return -101;
 }

@@ -157,6 +157,28 @@ def test_emulated_core_every_opcode(emu, oracle):
     assert seen == set(range(10))
 
 
+@pytest.mark.parametrize("Q,RL", [(16, 5), (4, 9), (16, 7), (32, 5)])
+def test_emulated_core_big_leaves(emu, oracle, Q, RL):
+    """Leaf nodes of 128..1024 elements as the whole code, as a right child and as a left child:
+    the wide (16-byte) spc / plane paths with the node in LDS, at the LDS boundary and in scratch."""
+    F = 4 * Q + 2
+    for M in (7, 8, 9, 10):
+        N = 1 << M
+        shapes = []
+        fr = np.zeros(N, np.uint8); fr[0] = 1; shapes.append(fr)                       # spc at the top
+        fr = np.ones(N, np.uint8); fr[N // 2 + 1:] = 0; shapes.append(fr)              # rate0_right, spc, rate0_comb
+        fr = np.zeros(N, np.uint8); fr[0] = 1; fr[N // 2] = 0; shapes.append(fr)       # left, spc, rate1_comb
+        fr = np.zeros(N, np.uint8); fr[0] = 1; fr[N // 2] = 1; shapes.append(fr)       # left, spc, right, spc, comb
+        fr = np.ones(N, np.uint8); fr[N - 1] = 0; fr[N // 4 + 1: N // 2] = 0; shapes.append(fr)  # spc below a rep-side sibling
+        for k, fr in enumerate(shapes):
+            prog = oracle.compile(fr, M)
+            K = int((fr == 0).sum())
+            cw = oracle.encode(pm1_message(40 + k, K, F), fr, M, 0)
+            for fam in ("awgn-1", "small"):
+                llr = family_llr(fam, 17 + k, cw)
+                assert (_emu_decode(emu, llr, prog, Q, RL) == oracle.decode(llr, prog)).all(), (M, k, fam)
+
+
 def test_emulated_core_golden_digest(emu, oracle, golden):
     """The emulated device core reproduces the reference's own output digest at N = 4096."""
     meta, _ = golden
