@@ -220,7 +220,11 @@ template <int Q> struct InVec {
 	{
 		if (Q % 4 == 0) { // four consecutive quads of one row: rows are 16-byte aligned then
 			int i = t / Q, q = t % Q;
+#if defined(POLAR_NT_INPUT) && !defined(POLAR_EMU)
+			return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + (size_t)i * stride + 4 * q));
+#else
 			return *reinterpret_cast<const u32x4 *>(p + (size_t)i * stride + 4 * q);
+#endif
 		}
 		u32x4 v;
 		v.x = ld(t); v.y = ld(t + 1); v.z = ld(t + 2); v.w = ld(t + 3);

@@ -19,3 +19,6 @@ done
 grep "^M " $OUT/trace.log > $OUT/summary.txt
 python3 tools/prof_summary.py $OUT >> $OUT/summary.txt 2>&1 || true
 cat $OUT/summary.txt
+# keep the summary and the kernel stats table, drop the bulky raw traces (gpurun_out/ is capped at 64 MiB)
+cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv 2>/dev/null || true
+rm -rf $OUT/trace $OUT/pmc[0-9]*/
