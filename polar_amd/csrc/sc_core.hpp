@@ -89,6 +89,8 @@ PDEV u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, se
 // of one lane are visible to the others: a single wavefront executes its DS / VMEM
 // instructions in order, so only the compiler has to be kept from reordering.
 PDEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+// nonzero in any lane (wave-uniform result); the host emulation ORs lane after lane instead
+PDEV u32 wave_any(u32 v) { return __builtin_amdgcn_ballot_w64(v != 0) != 0; }
 #endif
 
 PDEV int chain_depth(u32 pad) { return (int)(pad & 3); }
@@ -135,6 +137,16 @@ PDEV u32 madd4(u32 hs, u32 hz, u32 a, u32 b)
 	u32 rl = bfi(mask_lo(hs), pk_sub_sat(bl, al), pk_add_sat(bl, al));
 	rh = bfi(mask_hi(hz), bh, rh);
 	rl = bfi(mask_lo(hz), bl, rl);
+	return merge(rh, rl);
+}
+// madd with a partial sum that is known to be +1 / -1 (no erasure): vqadd(vsign(vmax(a,-127), h), b)
+PDEV u32 madd4_nz(u32 hs, u32 a, u32 b)
+{
+	const u32 K = 0x81008100u;
+	u32 ah = pk_max(split_hi(a), K), al = pk_max(split_lo(a), K);
+	u32 bh = split_hi(b), bl = split_lo(b);
+	u32 rh = bfi(mask_hi(hs), pk_sub_sat(bh, ah), pk_add_sat(bh, ah));
+	u32 rl = bfi(mask_lo(hs), pk_sub_sat(bl, al), pk_add_sat(bl, al));
 	return merge(rh, rl);
 }
 // bit 7 of every byte that equals zero
@@ -301,6 +313,11 @@ struct Group {
 	InVec<Q> in;
 	OutRows<Q> out;
 	int top;
+	// Zero planes in scratch are only written for nodes that hold an erasure (decision 0), which
+	// is rare: bit l of zc = the last completed level-l node (l > RL) has a valid, non-empty zero
+	// plane; zl = the same for the completed left child waiting at level l. Clear bit: the
+	// plane words of that node are undefined and read as "no erasure". Wave-uniform.
+	u32 zc, zl;
 #ifdef POLAR_PROFILE
 	unsigned long long *prof; // [16 node kinds][32 levels][cycles, calls], diagnostic build only
 #endif
@@ -378,21 +395,24 @@ struct Group {
 	// loads the 2^D source words t + j*nd, folds them stage by stage in registers and stores the
 	// level lvl-k words t + j*nd, j < 2^(D-k), after stage k: every level is written once and
 	// the re-read by the next `left` of the unfused program never happens.
-	template <class H>
+	// HZ: the zero plane of the decided child is valid and may hold erasures
+	template <bool HZ, class H>
 	PDEV u32 madd_at(const H *hs, const H *hz, u32 eb, int t, u32 x, u32 y) const
 	{
 		u32 e = eb + (u32)(t / Q);
 		int i = pidx(e, t % Q), sh = (int)(e & 7);
+		if (!HZ)
+			return madd4_nz(hs[i] << sh, x, y);
 		return madd4(hs[i] << sh, hz[i] << sh, x, y);
 	}
-	template <class H>
+	template <bool HZ, class H>
 	PDEV u32x4 madd_at(const H *hs, const H *hz, u32 eb, int t, u32x4 x, u32x4 y) const
 	{
 		u32x4 r;
-		r.x = madd_at(hs, hz, eb, t, x.x, y.x);
-		r.y = madd_at(hs, hz, eb, t + 1, x.y, y.y);
-		r.z = madd_at(hs, hz, eb, t + 2, x.z, y.z);
-		r.w = madd_at(hs, hz, eb, t + 3, x.w, y.w);
+		r.x = madd_at<HZ>(hs, hz, eb, t, x.x, y.x);
+		r.y = madd_at<HZ>(hs, hz, eb, t + 1, x.y, y.y);
+		r.z = madd_at<HZ>(hs, hz, eb, t + 2, x.z, y.z);
+		r.w = madd_at<HZ>(hs, hz, eb, t + 3, x.w, y.w);
 		return r;
 	}
 	static PDEV u32 ldE(const LVec &v, int t, u32) { return v.ld(t); }
@@ -418,7 +438,7 @@ struct Group {
 	}
 	// U independent final indices t, t + step, ... per lane: all 2^D * U loads are issued before
 	// the first use, which is what keeps enough bytes in flight for the HBM-resident levels
-	template <int D, class E, int U, class A, class H>
+	template <int D, bool HZ, class E, int U, class A, class H>
 	PDEV void chain_lane(const A &a, int lvl, u32 pad, const H *hs, const H *hz, u32 eb, int t, int nd, int step)
 	{
 		E x[U][1 << D];
@@ -445,7 +465,7 @@ struct Group {
 				} else {
 #pragma unroll
 					for (int j = 0; j < half; ++j)
-						x[u][j] = madd_at(hs, hz, eb, tu + j * nd, x[u][j], x[u][j + half]);
+						x[u][j] = madd_at<HZ>(hs, hz, eb, tu + j * nd, x[u][j], x[u][j + half]);
 				}
 				if (!chain_skip(pad, k)) {
 #pragma unroll
@@ -455,7 +475,7 @@ struct Group {
 			}
 		}
 	}
-	template <int D, class A, class H>
+	template <int D, bool HZ, class A, class H>
 	PDEV void chain_run(const A &a, int lvl, u32 pad, const H *hs, const H *hz, u32 eb)
 	{
 		int nd = Q << (lvl - D);
@@ -464,17 +484,17 @@ struct Group {
 		if (U > 1 && nd >= 256 * U) {
 			PFOR_LANES(lane) {
 				for (int t = lane * 4; t < nd; t += 256 * U)
-					chain_lane<D, u32x4, U>(a, lvl, pad, hs, hz, eb, t, nd, 256);
+					chain_lane<D, HZ, u32x4, U>(a, lvl, pad, hs, hz, eb, t, nd, 256);
 			}
 		} else if (nd >= 256) {
 			PFOR_LANES(lane) {
 				for (int t = lane * 4; t < nd; t += 256)
-					chain_lane<D, u32x4, 1>(a, lvl, pad, hs, hz, eb, t, nd, 0);
+					chain_lane<D, HZ, u32x4, 1>(a, lvl, pad, hs, hz, eb, t, nd, 0);
 			}
 		} else {
 			PFOR_LANES(lane) {
 				for (int t = lane; t < nd; t += 64)
-					chain_lane<D, u32, 1>(a, lvl, pad, hs, hz, eb, t, nd, 0);
+					chain_lane<D, HZ, u32, 1>(a, lvl, pad, hs, hz, eb, t, nd, 0);
 			}
 		}
 		wave_sync();
@@ -486,21 +506,37 @@ struct Group {
 		if (lvl - 1 <= RL) {
 			u32 eb = hrd & (u32)(W - 1);
 			if (lvl == top)
-				chain_run<D>(in, lvl, pad, hls, hlz, eb);
+				chain_run<D, true>(in, lvl, pad, hls, hlz, eb);
 			else if (lvl > RL)
-				chain_run<D>(GVec{sg + (Q << lvl)}, lvl, pad, hls, hlz, eb);
+				chain_run<D, true>(GVec{sg + (Q << lvl)}, lvl, pad, hls, hlz, eb);
 			else
-				chain_run<D>(LVec{sl + (Q << lvl)}, lvl, pad, hls, hlz, eb);
-		} else {
+				chain_run<D, true>(LVec{sl + (Q << lvl)}, lvl, pad, hls, hlz, eb);
+		} else { // scratch planes: only reached when the child's zero plane is empty (chain())
 			if (lvl == top)
-				chain_run<D>(in, lvl, pad, hgs, hgz, hrd);
+				chain_run<D, false>(in, lvl, pad, hgs, hgz, hrd);
 			else
-				chain_run<D>(GVec{sg + (Q << lvl)}, lvl, pad, hgs, hgz, hrd);
+				chain_run<D, false>(GVec{sg + (Q << lvl)}, lvl, pad, hgs, hgz, hrd);
 		}
 	}
 	PDEV void chain(int lvl, u32 hrd, u32 pad)
 	{
-		switch (chain_depth(pad)) {
+		int depth = chain_depth(pad);
+		if (chain_kind(pad, 1) == 1) { // leading `right`: its left sibling (level lvl-1) is decided
+			u32 bit = 1u << (lvl - 1);
+			zl = (zl & ~bit) | (zc & bit);
+			if (lvl - 1 > RL && (zc & bit)) {
+				// rare: the sibling holds erasures; run the stages one by one with the zero plane
+				soft_pass<1>(lvl, hrd);
+				for (int k = 2; k <= depth; ++k) {
+					if (chain_kind(pad, k) == 0)
+						soft_pass<0>(lvl - k + 1, 0);
+					else
+						soft_pass<2>(lvl - k + 1, 0);
+				}
+				return;
+			}
+		}
+		switch (depth) {
 		case 1: chain_at<1>(lvl, hrd, pad); break;
 		case 2: chain_at<2>(lvl, hrd, pad); break;
 		default: chain_at<3>(lvl, hrd, pad); break;
@@ -508,12 +544,13 @@ struct Group {
 	}
 
 	// comb / rate0_comb (polar_decoder.hh:52-67): node of level lvl at hrd; RATE0: left half is all +1.
-	// c: the children's planes (c.eb = left child), o: the node's planes.
-	template <bool RATE0, class TC, class TO>
-	PDEV void comb(int lvl, Planes<TC> c, Planes<TO> o, bool inplace)
+	// Node and children in the LDS window (lvl <= RL), in place.
+	template <bool RATE0>
+	PDEV void comb_lds(int lvl, u32 hrd)
 	{
+		Planes<lds_u32> o = lplanes(hrd);
 		int h = 1 << (lvl - 1);
-		if (h < 8) { // both halves share one octet (always in LDS: lvl <= 3)
+		if (h < 8) { // both halves share one octet
 			int j0 = (int)(o.eb & 7);
 			u32 lowm = span_mask(j0, h);
 			PFOR_LANES(lane) {
@@ -533,68 +570,140 @@ struct Group {
 			}
 		} else {
 			int n = (h >> 3) * Q; // plane dwords per half
-			int il0 = pidx(c.eb, 0), ir0 = pidx(c.eb + h, 0), ol0 = pidx(o.eb, 0), or0 = pidx(o.eb + h, 0);
-			if (n >= 256) { // 16-byte accesses, U of them in flight per array and lane
-				const int U = 4;
-				PFOR_LANES(lane) {
-					for (int t0 = lane * 4; t0 < n; t0 += 256 * U) {
-						u32x4 ls[U], lz[U], rs[U], rz[U];
-#pragma unroll
-						for (int u = 0; u < U; ++u) {
-							int t = t0 + 256 * u;
-							if (t < n) {
-								rs[u] = ldp4(c.s + ir0 + t);
-								rz[u] = ldp4(c.z + ir0 + t);
-								if (!RATE0) {
-									ls[u] = ldp4(c.s + il0 + t);
-									lz[u] = ldp4(c.z + il0 + t);
-								}
-							}
-						}
-#pragma unroll
-						for (int u = 0; u < U; ++u) {
-							int t = t0 + 256 * u;
-							if (t < n) {
-								stp4(o.s + ol0 + t, RATE0 ? rs[u] : ls[u] ^ rs[u]);
-								stp4(o.z + ol0 + t, RATE0 ? rz[u] : lz[u] | rz[u]);
-								if (!inplace) {
-									stp4(o.s + or0 + t, rs[u]);
-									stp4(o.z + or0 + t, rz[u]);
-								}
-							}
-						}
-					}
-				}
-			} else {
-				PFOR_LANES(lane) {
-					for (int t = lane; t < n; t += 64) {
-						u32 rs = c.s[ir0 + t], rz = c.z[ir0 + t];
-						if (RATE0) {
-							o.s[ol0 + t] = rs;
-							o.z[ol0 + t] = rz;
-						} else {
-							o.s[ol0 + t] = c.s[il0 + t] ^ rs;
-							o.z[ol0 + t] = c.z[il0 + t] | rz;
-						}
-						if (!inplace) {
-							o.s[or0 + t] = rs;
-							o.z[or0 + t] = rz;
-						}
-					}
+			int l0 = pidx(o.eb, 0), r0 = l0 + n;
+			PFOR_LANES(lane) {
+				for (int t = lane; t < n; t += 64) {
+					u32 rs = o.s[r0 + t], rz = o.z[r0 + t];
+					o.s[l0 + t] = RATE0 ? rs : o.s[l0 + t] ^ rs;
+					o.z[l0 + t] = RATE0 ? rz : o.z[l0 + t] | rz;
 				}
 			}
 		}
+		wave_sync();
+	}
+	// d[t] = a[t] (op) b[t] over n plane dwords, 16-byte accesses with U of them in flight per
+	// array and lane once the arrays are long enough. MODE 0: copy b, 1: a ^ b, 2: a | b,
+	// 3: fill with zero. Returns "any result word nonzero" (wave-uniform).
+	template <int MODE, class TD, class TA, class TB>
+	PDEV u32 plane_op(TD *d, const TA *a, const TB *b, int n)
+	{
+		u32 any = 0;
+		if (Q % 4 == 0 && n >= 256) {
+			const int U = 4;
+			PFOR_LANES(lane) {
+				u32 acc = 0;
+				for (int t0 = lane * 4; t0 < n; t0 += 256 * U) {
+					u32x4 x[U], y[U];
+#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						int t = t0 + 256 * u;
+						if (t < n) {
+							if (MODE != 3)
+								y[u] = ldp4(b + t);
+							if (MODE == 1 || MODE == 2)
+								x[u] = ldp4(a + t);
+						}
+					}
+#pragma unroll
+					for (int u = 0; u < U; ++u) {
+						int t = t0 + 256 * u;
+						if (t < n) {
+							u32x4 r;
+							if (MODE == 3) {
+								r.x = r.y = r.z = r.w = 0;
+							} else if (MODE == 0) {
+								r = y[u];
+							} else if (MODE == 1) {
+								r.x = x[u].x ^ y[u].x; r.y = x[u].y ^ y[u].y; r.z = x[u].z ^ y[u].z; r.w = x[u].w ^ y[u].w;
+							} else {
+								r.x = x[u].x | y[u].x; r.y = x[u].y | y[u].y; r.z = x[u].z | y[u].z; r.w = x[u].w | y[u].w;
+							}
+							acc |= r.x | r.y | r.z | r.w;
+							stp4(d + t, r);
+						}
+					}
+				}
+				any |= wave_any(acc);
+			}
+		} else {
+			PFOR_LANES(lane) {
+				u32 acc = 0;
+				for (int t = lane; t < n; t += 64) {
+					u32 r = MODE == 3 ? 0u : MODE == 0 ? b[t] : MODE == 1 ? a[t] ^ b[t] : a[t] | b[t];
+					acc |= r;
+					d[t] = r;
+				}
+				any |= wave_any(acc);
+			}
+		}
+		return any;
+	}
+	// any word of the n-dword LDS array nonzero (wave-uniform)
+	PDEV u32 lds_any(const lds_u32 *a, int n)
+	{
+		u32 any = 0;
+		PFOR_LANES(lane) {
+			u32 acc = 0;
+			for (int t = lane; t < n; t += 64)
+				acc |= a[t];
+			any |= wave_any(acc);
+		}
+		return any;
+	}
+	PDEV void set_zc(int lvl, u32 any) { zc = (zc & ~(1u << lvl)) | ((any ? 1u : 0u) << lvl); }
+	// Node of level RL+1: the children fill the LDS window, the node's planes go to scratch.
+	template <bool RATE0>
+	PDEV void comb_up(int lvl, u32 hrd)
+	{
+		int n = ((1 << (lvl - 1)) >> 3) * Q; // plane dwords per half; the left child starts the window
+		u32 *os = hgs + pidx(hrd, 0), *oz = hgz + pidx(hrd, 0);
+		if (RATE0)
+			plane_op<0>(os, hls, hls + n, n);
+		else
+			plane_op<1>(os, hls, hls + n, n);
+		plane_op<0>(os + n, hls, hls + n, n);
+		u32 any = RATE0 ? lds_any(hlz + n, n) : lds_any(hlz, 2 * n);
+		if (any) {
+			if (RATE0)
+				plane_op<0>(oz, hlz, hlz + n, n);
+			else
+				plane_op<2>(oz, hlz, hlz + n, n);
+			plane_op<0>(oz + n, hlz, hlz + n, n);
+		}
+		set_zc(lvl, any);
+		wave_sync();
+	}
+	// Node above level RL+1: children and node in scratch, in place; zero planes only where valid.
+	template <bool RATE0>
+	PDEV void comb_global(int lvl, u32 hrd)
+	{
+		int n = ((1 << (lvl - 1)) >> 3) * Q;
+		u32 *ls = hgs + pidx(hrd, 0), *lz = hgz + pidx(hrd, 0);
+		u32 fl = RATE0 ? 0u : (zl >> (lvl - 1)) & 1u, fr = (zc >> (lvl - 1)) & 1u;
+		if (RATE0)
+			plane_op<0>(ls, ls, ls + n, n);
+		else
+			plane_op<1>(ls, ls, ls + n, n);
+		if (fl | fr) {
+			if (!fr)
+				plane_op<3>(lz + n, lz, lz, n); // the right half becomes valid: no erasures there
+			else if (!fl)
+				plane_op<0>(lz, lz, lz + n, n); // left = 0 | right
+			else
+				plane_op<2>(lz, lz, lz + n, n);
+		}
+		set_zc(lvl, fl | fr);
 		wave_sync();
 	}
 	template <bool RATE0>
 	PDEV void comb_any(int lvl, u32 hrd)
 	{
 		if (lvl <= RL)
-			comb<RATE0>(lvl, lplanes(hrd), lplanes(hrd), true);
+			comb_lds<RATE0>(lvl, hrd);
 		else if (lvl == RL + 1)
-			comb<RATE0>(lvl, lplanes(hrd), gplanes(hrd), false);
+			comb_up<RATE0>(lvl, hrd);
 		else
-			comb<RATE0>(lvl, gplanes(hrd), gplanes(hrd), true);
+			comb_global<RATE0>(lvl, hrd);
 	}
 
 	// store a node's decision bits; s / z hold element j of the item at bit 7-j (normalised)
@@ -746,39 +855,43 @@ struct Group {
 
 	// ---- leaves of 16 elements and more: all lanes, one (octet, quad) item each ----
 	// tmp: 4*(len/8)*Q dwords of scratch (the dead LLR region below the node)
+	// wz: write the zero plane even when it is empty (LDS window); without it (scratch planes) an
+	// empty zero plane is left unwritten. Returns "the node holds an erasure" (wave-uniform).
 	template <class SRC, class T>
-	PDEV void leaf_big(u32 op, int lvl, const SRC &src, Planes<T> p, T *tmp, u32 row)
+	PDEV u32 leaf_big(u32 op, int lvl, const SRC &src, Planes<T> p, T *tmp, u32 row, bool wz)
 	{
 		int len = 1 << lvl, noct = len >> 3, n = noct * Q;
 		int i0 = pidx(p.eb, 0);
+		u32 any = 0;
 		if (op == OP_RATE0) {
-			PFOR_LANES(lane) {
-				for (int t = lane; t < n; t += 64) {
-					p.s[i0 + t] = 0;
-					p.z[i0 + t] = 0;
-				}
-			}
+			plane_op<3>(p.s + i0, p.s, p.s, n);
+			if (wz)
+				plane_op<3>(p.z + i0, p.z, p.z, n);
 			wave_sync();
-			return;
+			return 0;
 		}
 		if (op == OP_REP) { // the halving passes have left the sum in the level-0 region
 			lds_u32 *s0 = sl + Q;
 			PFOR_LANES(lane) {
+				u32 acc = 0;
 				for (int t = lane; t < n; t += 64) {
 					int q = t % Q;
 					u32 x = s0[q], zb = zero_bytes(x);
 					p.s[i0 + t] = byte_mask(x);
 					p.z[i0 + t] = byte_mask(zb);
+					acc |= zb;
 					if (t < Q)
 						out.st(row, q, symbols(x, zb));
 				}
+				any |= wave_any(acc);
 			}
 			wave_sync();
-			return;
+			return any;
 		}
 		T *ts = tmp, *tz = tmp + n, *mins = tmp + 2 * n;
 		if (op == OP_RATE1) {
 			PFOR_LANES(lane) {
+				u32 acc = 0;
 				for (int t = lane; t < n; t += 64) {
 					int o = t / Q, q = t % Q;
 					u32 s = 0, z = 0;
@@ -790,19 +903,21 @@ struct Group {
 					}
 					p.s[i0 + t] = s;
 					p.z[i0 + t] = z;
+					acc |= z;
 					trans_octet(s, z, 8);
 					ts[t] = s;
 					tz[t] = z;
 				}
+				any |= wave_any(acc);
 			}
 			wave_sync();
 			trans_emit(ts, tz, len, 0, row);
-			return;
+			return any;
 		}
 		// spc (polar_decoder.hh:107-127)
 		if (WIDE_LEAVES && n >= 256) {
-			spc_wide(lvl, src, p, tmp, sl + Q, row);
-			return;
+			spc_wide(lvl, src, p, tmp, sl + Q, row, wz);
+			return 0;
 		}
 		PFOR_LANES(lane) {
 			for (int t = lane; t < n; t += 64) {
@@ -850,7 +965,8 @@ struct Group {
 					s ^= tie & odd;
 				}
 				p.s[i0 + t] = s;
-				p.z[i0 + t] = 0;
+				if (wz)
+					p.z[i0 + t] = 0;
 				trans_octet(s, z, 8);
 				ts[t] = s;
 				tz[t] = 0;
@@ -858,6 +974,7 @@ struct Group {
 		}
 		wave_sync();
 		trans_emit(ts, tz, len, 1, row);
+		return 0; // a parity-check node never decides 0 (polar_decoder.hh:107-127)
 	}
 
 	// spc (polar_decoder.hh:107-127) for nodes of >= 256 plane dwords: every lane owns four frame
@@ -865,7 +982,7 @@ struct Group {
 	// and has its eight 16-byte loads in flight together. red: 768 dwords of LDS.
 	static const bool WIDE_LEAVES = Q % 4 == 0 && LDS_SOFT >= Q + 768;
 	template <class SRC, class T>
-	PDEV void spc_wide(int lvl, const SRC &src, Planes<T> p, T *tmp, lds_u32 *red, u32 row)
+	PDEV void spc_wide(int lvl, const SRC &src, Planes<T> p, T *tmp, lds_u32 *red, u32 row, bool wz)
 	{
 		int len = 1 << lvl, n = (len >> 3) * Q;
 		int i0 = pidx(p.eb, 0);
@@ -951,7 +1068,8 @@ struct Group {
 				zero.x = zero.y = zero.z = zero.w = 0;
 				sv.x = sg4[0]; sv.y = sg4[1]; sv.z = sg4[2]; sv.w = sg4[3];
 				stp4(p.s + i0 + t, sv);
-				stp4(p.z + i0 + t, zero);
+				if (wz)
+					stp4(p.z + i0 + t, zero);
 #pragma unroll
 				for (int c = 0; c < 4; ++c) {
 					u32 z = 0;
@@ -979,19 +1097,21 @@ struct Group {
 				leaf_small(op, lvl, LVec{sl + (Q << lvl)}, hrd, row);
 		} else if (lvl <= RL) {
 			if (lvl == top)
-				leaf_big(op, lvl, in, lplanes(hrd), sl + n4, row);
+				leaf_big(op, lvl, in, lplanes(hrd), sl + n4, row, true);
 			else
-				leaf_big(op, lvl, LVec{sl + (Q << lvl)}, lplanes(hrd), sl + n4, row);
+				leaf_big(op, lvl, LVec{sl + (Q << lvl)}, lplanes(hrd), sl + n4, row, true);
 		} else {
-			leaf_big(op, lvl, any_src(lvl), fplanes(lvl, hrd), fregion(lvl - 1), row);
+			set_zc(lvl, leaf_big(op, lvl, any_src(lvl), gplanes(hrd), fregion(lvl - 1), row, false));
 		}
 	}
 
 	// rate1_comb (polar_decoder.hh:76-84): node of level lvl at hrd, left child decided.
 	// c: children's planes (left child at c.eb), o: the node's planes, tmp: 2*max(1,h/8)*Q dwords
+	// fl: the left child's zero plane is valid. Returns "the node holds an erasure".
 	template <class SRC, class TC, class TO, class T>
-	PDEV void rate1_comb(int lvl, const SRC &src, Planes<TC> c, Planes<TO> o, T *tmp, u32 row)
+	PDEV u32 rate1_comb(int lvl, const SRC &src, Planes<TC> c, Planes<TO> o, T *tmp, u32 row, u32 fl)
 	{
+		u32 any = 0;
 		int h = 1 << (lvl - 1);
 		int noct = h >= 8 ? h >> 3 : 1, per = h >= 8 ? 8 : h;
 		int n = noct * Q;
@@ -999,9 +1119,10 @@ struct Group {
 		int j0 = (int)(o.eb & 7); // nonzero only when the whole node fits one octet
 		int il0 = pidx(c.eb, 0), ol0 = pidx(o.eb, 0), or0 = pidx(o.eb + h, 0);
 		PFOR_LANES(lane) {
+			u32 acc = 0;
 			for (int t = lane; t < n; t += 64) {
 				int oc = t / Q, q = t % Q;
-				u32 ls = c.s[il0 + t], lz = c.z[il0 + t];
+				u32 ls = c.s[il0 + t], lz = fl ? c.z[il0 + t] : 0u;
 				u32 rs = 0, rz = 0;
 #pragma unroll
 				for (int j = 0; j < 8; ++j)
@@ -1025,6 +1146,7 @@ struct Group {
 					o.s[ol0 + t] = s;
 					o.z[ol0 + t] = z;
 				}
+				acc |= lz | rz;
 				trans_octet(rs, rz, per);
 				if (h <= 8) {
 					emit_octet(rs, rz, h, 0, row, q);
@@ -1033,10 +1155,12 @@ struct Group {
 					tz[t] = rz;
 				}
 			}
+			any |= wave_any(acc);
 		}
 		wave_sync();
 		if (h > 8)
 			trans_emit(ts, tz, h, 0, row);
+		return any;
 	}
 	PDEV void rate1_comb_any(int lvl, u32 hrd, u32 row)
 	{
@@ -1044,11 +1168,12 @@ struct Group {
 		if (lvl <= RL) {
 			lds_u32 *tmp = sl + (Q << (lvl - 1));
 			if (lvl == top)
-				rate1_comb(lvl, in, lplanes(hrd), lplanes(hrd), tmp, row);
+				rate1_comb(lvl, in, lplanes(hrd), lplanes(hrd), tmp, row, 1u);
 			else
-				rate1_comb(lvl, LVec{sl + (Q << lvl)}, lplanes(hrd), lplanes(hrd), tmp, row);
+				rate1_comb(lvl, LVec{sl + (Q << lvl)}, lplanes(hrd), lplanes(hrd), tmp, row, 1u);
 		} else {
-			rate1_comb(lvl, any_src(lvl), fplanes(lvl - 1, hrd), fplanes(lvl, hrd), fregion(lvl - 1), row);
+			u32 fl = lvl - 1 > RL ? (zc >> (lvl - 1)) & 1u : 1u;
+			set_zc(lvl, rate1_comb(lvl, any_src(lvl), fplanes(lvl - 1, hrd), gplanes(hrd), fregion(lvl - 1), row, fl));
 		}
 	}
 
@@ -1056,9 +1181,6 @@ struct Group {
 	{
 		switch (op) {
 		case OP_CHAIN: chain(lvl, hrd, pad); break;
-		case OP_LEFT: soft_pass<0>(lvl, hrd); break;
-		case OP_RIGHT: soft_pass<1>(lvl, hrd); break;
-		case OP_RATE0_RIGHT: soft_pass<2>(lvl, hrd); break;
 		case OP_COMB: comb_any<false>(lvl, hrd); break;
 		case OP_RATE0_COMB: comb_any<true>(lvl, hrd); break;
 		case OP_RATE1_COMB: rate1_comb_any(lvl, hrd, row); break;
@@ -1081,6 +1203,7 @@ struct Group {
 	template <class P>
 	PDEV void run(P prog)
 	{
+		zc = zl = 0;
 		DevOp cur = fetch(prog, 0);
 		for (int pc = 1;; ++pc) {
 			u32 op = cur.op_level & 255, hrd = cur.hrd, row = cur.row, pad = cur.pad;
