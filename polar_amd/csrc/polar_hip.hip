@@ -422,17 +422,38 @@ extern "C" int polar_hip_load_program(polar_hip_handle *h, const uint8_t *progra
 	return (int)h->programs.size() - 1;
 }
 
-static const KernelVariant *pick_variant(const polar_hip_handle *h, int top)
+static const KernelVariant *find_variant(int q, int rl)
 {
-	int fpw = h->cfg_frames_per_wave, rl = h->cfg_lds_level;
-	if (!fpw) { // default: most resident wavefronts (measured best at N = 2^16)
-		fpw = 64;
-		rl = 6;
-		(void)top;
-	}
 	for (const KernelVariant &v : g_variants)
-		if (4 * v.q == fpw && v.rl == rl)
+		if (v.q == q && v.rl == rl)
 			return &v;
+	return nullptr;
+}
+
+// Bytes of scratch one wavefront needs: LLR levels above the LDS levels plus two partial-sum planes.
+static size_t scratch_bytes_per_wave(int q, int top)
+{
+	size_t soft = (size_t)q << top;
+	return (soft + 2 * (soft / 8)) * sizeof(u32);
+}
+
+// Default shape: the ~20 KB-of-LDS family (7 wavefronts per CU), widest first. 128 frames per
+// wavefront measured best at N = 2^16; narrower groups when the batch is too small
+// to give every resident wavefront a group, or when the scratch arenas would not fit.
+static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, size_t frames, size_t scratch_cap)
+{
+	if (h->cfg_frames_per_wave)
+		return find_variant(h->cfg_frames_per_wave / 4, h->cfg_lds_level);
+	const size_t resident = (size_t)7 * h->cus;
+	static const int family[][2] = {{32, 6}, {16, 7}, {8, 8}, {4, 9}, {2, 10}, {1, 11}};
+	for (const auto &f : family) {
+		size_t groups = (frames + 4 * f[0] - 1) / (4 * f[0]);
+		if (f[0] > 1 && groups < resident)
+			continue;
+		if (f[0] > 1 && top > f[1] && resident * scratch_bytes_per_wave(f[0], top) > scratch_cap)
+			continue;
+		return find_variant(f[0], f[1]);
+	}
 	return nullptr;
 }
 
@@ -442,7 +463,10 @@ static const KernelVariant *pick_variant(const polar_hip_handle *h, int top)
 static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, hipStream_t stream, bool timed)
 {
 	LoadedProgram &lp = h->programs[program_id];
-	const KernelVariant *v = pick_variant(h, lp.host.top);
+	size_t free_b = 0, total_b = 0;
+	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+	const size_t scratch_cap = h->scratch.bytes + free_b / 2; // what is held already plus half of what is left
+	const KernelVariant *v = pick_variant(h, lp.host.top, frames, scratch_cap);
 	if (!v)
 		return fail(POLAR_E_ARG, "no kernel variant for the configured (frames_per_wave, lds_level)");
 	if (!lp.dev.count(v->q)) { // first use with this wavefront shape: fuse and upload
@@ -482,11 +506,21 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	size_t blocks = (size_t)per_cu * h->cus;
 	if (h->cfg_max_waves && (size_t)h->cfg_max_waves < blocks)
 		blocks = h->cfg_max_waves;
+	size_t block_dwords = 0;
+	if (lp.host.top > v->rl) { // LLR levels above the LDS levels and the partial-sum planes live in scratch
+		size_t soft = (size_t)v->q << lp.host.top;
+		block_dwords = soft + 2 * (soft / 8);
+		const size_t fit = scratch_cap / (block_dwords * sizeof(u32));
+		if (fit < 1)
+			return fail(POLAR_E_NOMEM, "not enough device memory for one wavefront's scratch arena");
+		if (blocks > fit) // fewer resident wavefronts, more sweeps
+			blocks = fit;
+	}
 	// every wavefront walks the same number of groups: no idle tail behind a last partial sweep
 	size_t sweeps = (groups + blocks - 1) / blocks;
 	blocks = (groups + sweeps - 1) / sweeps;
-	if (blocks >= 8 && blocks % 8)
-		blocks += 8 - blocks % 8; // multiple of 8 for the XCD-aware group order
+	if (blocks >= 8 && blocks % 8) // multiple of 8 for the XCD-aware group order
+		blocks = blocks + 8 - blocks % 8 <= (block_dwords ? scratch_cap / (block_dwords * sizeof(u32)) : blocks + 8) ? blocks + 8 - blocks % 8 : blocks - blocks % 8;
 	if (getenv("POLAR_HIP_DEBUG"))
 		fprintf(stderr, "polar_hip: decode Q=%d RL=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d\n", v->q, v->rl, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct);
 	DecodeArgs a;
@@ -501,10 +535,9 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	a.stagger_ticks = 0;
 	if (const char *e = getenv("POLAR_HIP_STAGGER_US"))
 		a.stagger_ticks = (u32)(atof(e) * 100.0);
-	if (lp.host.top > v->rl) {
-		size_t soft = (size_t)v->q << lp.host.top;
-		a.block_dwords = soft + 2 * (soft / 8);
-		if ((rc = h->scratch.reserve(blocks * a.block_dwords * sizeof(u32))))
+	if (block_dwords) {
+		a.block_dwords = block_dwords;
+		if ((rc = h->scratch.reserve(blocks * block_dwords * sizeof(u32))))
 			return rc;
 		a.scratch = (u32 *)h->scratch.p;
 	}

@@ -48,7 +48,7 @@ def test_decoder_golden_kats(session, oracle, golden):
         assert (out == arr[k["name"] + "_out"]).all(), k["name"]
 
 
-@pytest.mark.parametrize("M", [12, 14, 16])
+@pytest.mark.parametrize("M", [12, 14, 16, 20])
 def test_decoder_golden_digests(session, oracle, golden, M):
     meta, _ = golden
     N = 1 << M
@@ -61,7 +61,7 @@ def test_decoder_golden_digests(session, oracle, golden, M):
         assert "%016x" % fnv1a64(out) == k["out_fnv"], (M, k["family"])
 
 
-@pytest.mark.parametrize("fpw,rl", [(4, 11), (8, 10), (16, 9), (32, 8), (64, 7), (16, 10), (16, 8), (64, 6)])
+@pytest.mark.parametrize("fpw,rl", [(4, 11), (8, 10), (16, 9), (32, 8), (64, 7), (16, 10), (16, 8), (64, 6), (128, 6), (128, 5), (256, 5), (256, 4)])
 def test_decoder_vs_oracle_all_variants(session, oracle, fpw, rl):
     """Every built kernel variant, ragged frame counts (tail groups, unaligned rows)."""
     session.configure(fpw, rl, 0)
@@ -78,6 +78,28 @@ def test_decoder_vs_oracle_all_variants(session, oracle, fpw, rl):
                 for fam in ("awgn-1", "uniform", "small"):
                     llr = family_llr(fam, M + frames, cw)
                     assert (_decode(session, llr, prog, K) == oracle.decode(llr, prog)).all(), (M, frames, code, fam)
+    finally:
+        session.configure(0, 0, 0)
+
+
+@pytest.mark.parametrize("fpw,rl", [(128, 6), (128, 5), (64, 7), (256, 5)])
+def test_wide_variants_full_size_digest(session, oracle, golden, fpw, rl):
+    """The variants the default picks for big batches, on the reference's N = 2^16 digests: the
+    32 golden frames are embedded in a batch wide enough for whole 128/256-frame groups."""
+    meta, _ = golden
+    M = 16
+    N = 1 << M
+    fro = _code(oracle, M)
+    prog = oracle.compile(fro, M)
+    session.configure(fpw, rl, 0)
+    try:
+        for k in [k for k in meta["decoder_digests"] if k["M"] == M]:
+            cw = oracle.encode(pm1_message(k["msg_seed"], N // 2, k["frames"]), fro, M, 1)
+            llr = family_llr(k["family"], k["llr_seed"], cw)
+            wide = np.ascontiguousarray(np.tile(llr, (1, 9))[:, :fpw + 32 + 5])  # ragged: one full group + a tail
+            out = _decode(session, wide, prog, N // 2)
+            for a in range(0, wide.shape[1] - 31, 32):
+                assert "%016x" % fnv1a64(np.ascontiguousarray(out[:, a:a + 32])) == k["out_fnv"], (fpw, rl, k["family"], a)
     finally:
         session.configure(0, 0, 0)
 
