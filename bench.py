@@ -12,7 +12,9 @@ shard them with no other exchange (weak scaling: F frames per GPU).
 
 Inputs are synthetic and resident in HBM before the timed region: random +-1 messages,
 systematic encoding (PolarSysEnc, on device), BPSK/AWGN at Es/N0 = -1 dB, LLR = 2y/sigma^2
-quantised to int8 as testbench.cc:112-114,154-165 does.
+quantised to int8 as testbench.cc:112-114,154-165 does -- all on the device through the
+library's counter-based message source and channel, so the batch does not depend on how the
+frames are sharded over ranks.
 
 Prints ONE JSON line (rank 0). `value` = info bits decoded by all ranks / wall time of the K
 steps (max over ranks). `roofline` prices the decode kernel alone (HIP events on its launch
@@ -59,26 +61,24 @@ def make_code(polar_amd):
     return fro, prog[:n].copy()
 
 
-def generate(torch, polar_amd, sess, fro, prog, frames, seed, dev):
-    """Resident batch: llr [N][frames] int8 and the transmitted u-domain message [K][frames]."""
-    sigma = float(np.sqrt(1.0 / (2.0 * 10.0 ** (SNR_DB / 10.0))))
-    fact = 2.0 / (sigma * sigma)
+def generate(torch, polar_amd, sess, fro, prog, frames, seed, first_frame, dev):
+    """Resident batch: llr [N][frames] int8 and the transmitted u-domain message [K][frames].
+    Message bits and noise come from the library's counter-based source (polar_hip_random_message,
+    polar_hip_channel): global frame g is the same whatever rank or chunk produces it."""
     llr = torch.empty((N, frames), dtype=torch.int8, device=dev)
     u_true = torch.empty((K, frames), dtype=torch.int8, device=dev)
-    gen = torch.Generator(device=dev).manual_seed(seed)
     enc = polar_amd.PolarSysEnc(M, sess)
     dec = polar_amd.PolarDecoder(sess)
-    chunk = min(frames, 4096)
+    chunk = min(frames, 8192)
     stats = torch.zeros(4, dtype=torch.int64, device=dev)
     for a in range(0, frames, chunk):
         c = min(chunk, frames - a)
-        msg = (1 - 2 * torch.randint(0, 2, (K, c), generator=gen, device=dev, dtype=torch.int8)).contiguous()
+        msg = torch.empty((K, c), dtype=torch.int8, device=dev)
+        sess.random_message(msg, seed, first_frame + a)
         cw = torch.empty((N, c), dtype=torch.int8, device=dev)
         enc(cw, msg, fro)
-        y = cw.to(torch.float32)
-        y.add_(torch.randn(y.shape, generator=gen, device=dev), alpha=sigma)
-        q = torch.clamp(torch.round(y * fact), -128, 127).to(torch.int8).contiguous()
-        del y
+        q = torch.empty((N, c), dtype=torch.int8, device=dev)
+        sess.channel(q, cw, SNR_DB, seed, first_frame + a)
         sess.count(stats, q, cw, None, None)  # awgn_errors / quantization_erasures of the batch
         llr[:, a:a + c] = q
         # u-domain truth: decoding the noise-free codeword returns the encoder's input
@@ -157,7 +157,7 @@ def main():
         sess.configure(args.fpw, args.lds_level, 0)
     fro, prog = make_code(polar_amd)
     frames = args.frames
-    llr, u_true, chan = generate(torch, polar_amd, sess, fro, prog, frames, 42 + rank, dev)
+    llr, u_true, chan = generate(torch, polar_amd, sess, fro, prog, frames, 42, rank * frames, dev)
     out = torch.empty((K, frames), dtype=torch.int8, device=dev)
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
     dec = polar_amd.PolarDecoder(sess)

@@ -99,6 +99,31 @@ int polar_hip_systematic_extract(polar_hip_handle *h, int8_t *decoded, const uin
 int polar_hip_count(polar_hip_handle *h, int64_t *counters, const int8_t *noisy, const int8_t *orig, size_t n_code,
 	const int8_t *decoded, const int8_t *message, size_t n_mesg, int where);
 
+/* ---- the bench's message source and channel, moved onto the device ----
+ * The reference draws both from std::mt19937 streams (testbench.cc:63-67, 116-117), which cannot
+ * be split over GPUs. Here every value is a pure function of (seed, row, global frame index):
+ * Philox-4x32-10, key = seed, counter = (frame / 4 low, frame / 4 high, row, stream), stream
+ * 0 = noise, 1 = message; lane frame % 4 of the block. Any sharding of the frames
+ * [first_frame, first_frame + frames) over calls or GPUs therefore yields the same batch. */
+
+/* testbench.cc:126-127: message[row][f] = 1 - 2 * bit, bit = bit 0 of the frame's Philox word. */
+int polar_hip_random_message(polar_hip_handle *h, int8_t *message, size_t rows, size_t frames, uint64_t seed, uint64_t first_frame, int where);
+
+/* testbench.cc:112-114, 151-165: sigma = sqrt(1 / (2 * 10^(snr_db/10))), y = codeword + sigma * n
+ * with n ~ N(0,1) by Box-Muller in double from the Philox words (0,1) -> lanes 0,1 and (2,3) ->
+ * lanes 2,3; llr = PolarHelper<int8_t>::quant(2 / sigma^2 * y) (polar_helper.hh:194-198).
+ * codeword and llr: rows x frames; they may not alias. */
+int polar_hip_channel(polar_hip_handle *h, int8_t *llr, const int8_t *codeword, size_t rows, size_t frames, double snr_db, uint64_t seed, uint64_t first_frame, int where);
+
+/* One SNR point of the bench loop, testbench.cc:125-193, for frames [first_frame, first_frame +
+ * frames) entirely on the device: random message -> PolarEncoder / PolarSysEnc -> channel ->
+ * PolarDecoder -> (systematic: re-encode + gather) -> counters. Adds to counters[0..3] as
+ * polar_hip_count does, counters[4] += frames, counters[5] += frames * K (the BER denominator,
+ * testbench.cc:197). `where` places `counters` (int64[6]) on the host or the device (ready for
+ * the RCCL all-reduce across frame shards); the frame buffers are internal and chunked. */
+int polar_hip_simulate(polar_hip_handle *h, int program_id, const uint8_t *frozen, int level, int systematic, double snr_db,
+	uint64_t seed, uint64_t first_frame, size_t frames, int64_t *counters, int where);
+
 /* Blocks until all work enqueued through this handle has finished. */
 int polar_hip_synchronize(polar_hip_handle *h);
 

@@ -475,3 +475,58 @@ double oracle_decode_time(const int8_t *codeword, const uint8_t *program, size_t
 	free(msg);
 	return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* ---- message source and channel (include/polar_hip.h; testbench.cc:112-117, 126-127, 151-165) ---- */
+
+static uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+void oracle_philox4x32_10(uint32_t out[4], const uint32_t counter[4], const uint32_t key[2])
+{
+	uint32_t c[4] = {counter[0], counter[1], counter[2], counter[3]}, k[2] = {key[0], key[1]};
+	for (int round = 0; round < 10; ++round) {
+		if (round) { /* Weyl sequence on the key between rounds */
+			k[0] += 0x9E3779B9u;
+			k[1] += 0xBB67AE85u;
+		}
+		uint32_t hi0 = mulhi32(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+		uint32_t hi1 = mulhi32(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+		uint32_t n[4] = {hi1 ^ c[1] ^ k[0], lo1, hi0 ^ c[3] ^ k[1], lo0};
+		memcpy(c, n, sizeof c);
+	}
+	memcpy(out, c, sizeof c);
+}
+
+static void oracle_draw(uint32_t out[4], uint64_t seed, uint32_t stream, uint32_t row, uint64_t quad)
+{
+	uint32_t ctr[4] = {(uint32_t)quad, (uint32_t)(quad >> 32), row, stream}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+	oracle_philox4x32_10(out, ctr, key);
+}
+
+void oracle_random_message(int8_t *message, size_t rows, size_t frames, uint64_t seed, uint64_t first_frame)
+{
+	for (size_t i = 0; i < rows; ++i)
+		for (size_t f = 0; f < frames; ++f) {
+			uint64_t g = first_frame + f;
+			uint32_t w[4];
+			oracle_draw(w, seed, 1, (uint32_t)i, g >> 2);
+			message[i * frames + f] = (int8_t)(1 - 2 * (int)(w[g & 3] & 1));
+		}
+}
+
+void oracle_channel(int8_t *llr, const int8_t *codeword, size_t rows, size_t frames, double snr_db, uint64_t seed, uint64_t first_frame)
+{
+	double sigma = sqrt(1.0 / (2.0 * pow(10.0, snr_db / 10.0))); /* testbench.cc:112-114 */
+	double fact = 2.0 / (sigma * sigma);                            /* testbench.cc:162-163 */
+	for (size_t i = 0; i < rows; ++i)
+		for (size_t f = 0; f < frames; ++f) {
+			uint64_t g = first_frame + f;
+			uint32_t w[4];
+			oracle_draw(w, seed, 0, (uint32_t)i, g >> 2);
+			int pair = (int)(g & 2);
+			double u1 = ((double)w[pair] + 0.5) / 4294967296.0, u2 = ((double)w[pair + 1] + 0.5) / 4294967296.0;
+			double r = sqrt(-2.0 * log(u1)), t = 6.283185307179586476925286766559 * u2;
+			double n = (g & 1) ? r * sin(t) : r * cos(t);
+			double y = (double)codeword[i * frames + f] + sigma * n; /* testbench.cc:154-158 */
+			llr[i * frames + f] = oracle_quant(fact * y);           /* testbench.cc:164-165 */
+		}
+}

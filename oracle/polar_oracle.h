@@ -67,6 +67,16 @@ void oracle_systematic_extract(int8_t *decoded, const uint8_t *frozen, int level
 void oracle_count(int64_t counters[4], const int8_t *noisy, const int8_t *orig, size_t n_code,
 	const int8_t *decoded, const int8_t *message, size_t n_mesg);
 
+/* Message source and channel of the bench as include/polar_hip.h defines them for the device
+ * (counter-based, so they shard): Philox-4x32-10 restated from the published algorithm (Salmon,
+ * Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11; Random123 1.14
+ * philox.h), pinned by that library's known-answer vectors in tests/test_oracle_golden.py. */
+void oracle_philox4x32_10(uint32_t out[4], const uint32_t counter[4], const uint32_t key[2]);
+/* testbench.cc:126-127 */
+void oracle_random_message(int8_t *message, size_t rows, size_t frames, uint64_t seed, uint64_t first_frame);
+/* testbench.cc:112-114, 151-165 with quant of polar_helper.hh:194-198 */
+void oracle_channel(int8_t *llr, const int8_t *codeword, size_t rows, size_t frames, double snr_db, uint64_t seed, uint64_t first_frame);
+
 /* wall-clock seconds for `reps` decode calls on `frames` frames (cpu_baseline "port") */
 double oracle_decode_time(const int8_t *codeword, const uint8_t *program, size_t frames, int reps);
 

@@ -137,6 +137,27 @@ class Session:
         n_mesg = int(decoded.numel() if hasattr(decoded, "numel") else decoded.size) if decoded is not None else 0
         _check(lib.polar_hip_count(self._h, ptrs[0][0], ptrs[1][0], ptrs[2][0], n_code, ptrs[3][0], ptrs[4][0], n_mesg, where), "polar_hip_count")
 
+    def random_message(self, message, seed, first_frame=0):
+        """testbench.cc:126-127 with the counter-based generator of include/polar_hip.h:
+        message[K][frames] = 1 - 2 * bit for global frames first_frame, first_frame + 1, ..."""
+        p, where = _ptr(message)
+        _check(lib.polar_hip_random_message(self._h, p, int(message.shape[0]), _frames(message), int(seed), int(first_frame), where), "polar_hip_random_message")
+
+    def channel(self, llr, codeword, snr_db, seed, first_frame=0):
+        """testbench.cc:112-114, 151-165: BPSK + AWGN at Es/N0 = snr_db, LLR quantised to int8."""
+        (pl, wl), (pc, wc) = _ptr(llr), _ptr(codeword)
+        if tuple(llr.shape) != tuple(codeword.shape):
+            raise PolarError(-1, "channel: llr and codeword must have the same shape")
+        _check(lib.polar_hip_channel(self._h, pl, pc, int(codeword.shape[0]), _frames(codeword), float(snr_db), int(seed), int(first_frame), _where(wl, wc)), "polar_hip_channel")
+
+    def simulate(self, counters, program, frozen, level, systematic, snr_db, seed, first_frame, frames):
+        """One SNR point of testbench.cc:125-193 on the device; counters: int64[6] (host numpy or
+        device tensor), added to."""
+        pid, _rows = self.load_program(program)
+        fz = np.ascontiguousarray(frozen, dtype=np.uint8)
+        pc, where = _ptr(counters)
+        _check(lib.polar_hip_simulate(self._h, pid, fz.ctypes.data, int(level), int(bool(systematic)), float(snr_db), int(seed), int(first_frame), int(frames), pc, where), "polar_hip_simulate")
+
     def synchronize(self):
         _check(lib.polar_hip_synchronize(self._h), "polar_hip_synchronize")
 

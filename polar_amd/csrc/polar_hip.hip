@@ -19,6 +19,7 @@
 #include "../../include/polar_hip.h"
 #include "construct.hpp"
 #include "program.hpp"
+#include "channel.hpp"
 #include "sc_core.hpp"
 
 using namespace polar;
@@ -245,6 +246,42 @@ __global__ void __launch_bounds__(256) count_kernel(unsigned long long *c, const
 }
 
 // ---------------------------------------------------------------------------------------
+// message source and channel (channel.hpp): one thread per (row, global frame quad)
+// ---------------------------------------------------------------------------------------
+
+// MODE 0: llr = quant(fact * (cw + sigma * n)); MODE 1: msg = 1 - 2 * bit
+template <int MODE>
+__global__ void __launch_bounds__(256) channel_kernel(int8_t *out, const int8_t *cw, size_t rows, size_t frames, double sigma, double fact, uint64_t seed, uint64_t frame0)
+{
+	const uint64_t q0 = frame0 >> 2, nq = ((frame0 + frames - 1) >> 2) - q0 + 1;
+	const size_t items = rows * nq, nt = (size_t)gridDim.x * blockDim.x;
+	for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += nt) {
+		const size_t i = it / nq;
+		const uint64_t quad = q0 + it % nq;
+		PhiloxBlock b = draw(seed, MODE ? STREAM_MESSAGE : STREAM_NOISE, (uint32_t)i, quad);
+		double n[4] = {0, 0, 0, 0};
+		if (MODE == 0) {
+			normal_pair(b.v[0], b.v[1], n[0], n[1]);
+			normal_pair(b.v[2], b.v[3], n[2], n[3]);
+		}
+#pragma unroll
+		for (int c = 0; c < 4; ++c) {
+			uint64_t g = 4 * quad + c;
+			if (g < frame0 || g >= frame0 + frames)
+				continue;
+			size_t at = i * frames + (size_t)(g - frame0);
+			out[at] = MODE ? (int8_t)(1 - 2 * (int)(b.v[c] & 1)) : quant_llr(fact * ((double)cw[at] + sigma * n[c]));
+		}
+	}
+}
+
+__global__ void add_counters_kernel(unsigned long long *c, unsigned long long a, unsigned long long b)
+{
+	c[4] += a;
+	c[5] += b;
+}
+
+// ---------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------
 
@@ -286,6 +323,7 @@ struct polar_hip_handle {
 	bool timed = false;
 	std::vector<LoadedProgram> programs;
 	DeviceBuffer scratch, stage_in, stage_out, enc_tmp, tables, counters, pad_in, pad_out;
+	DeviceBuffer sim_cw, sim_llr, sim_msg, sim_dec; // polar_hip_simulate's chunk
 	std::vector<uint8_t> frozen_cache; // frozen set the device tables were built from
 	int cfg_frames_per_wave = 0, cfg_lds_level = 0, cfg_max_waves = 0;
 };
@@ -384,6 +422,10 @@ extern "C" void polar_hip_destroy(polar_hip_handle *h)
 	h->counters.release();
 	h->pad_in.release();
 	h->pad_out.release();
+	h->sim_cw.release();
+	h->sim_llr.release();
+	h->sim_msg.release();
+	h->sim_dec.release();
 	(void)hipEventDestroy(h->ev0);
 	(void)hipEventDestroy(h->ev1);
 	(void)hipStreamDestroy(h->stream);
@@ -749,6 +791,27 @@ extern "C" int polar_hip_encode(polar_hip_handle *h, int systematic, int8_t *cod
 	return POLAR_OK;
 }
 
+// decoded (device, K x frames, u domain) -> message estimate: re-encode into tmp (N x frames)
+// and gather the information rows (testbench.cc:177-183). Tables must be current.
+static int extract_device(polar_hip_handle *h, int8_t *dev, int8_t *tmp, int level, int K, size_t frames)
+{
+	size_t n = (size_t)1 << level;
+	int rc = encode_device(h, 0, tmp, dev, level, frames);
+	if (rc)
+		return rc;
+	const int *info_pos = (const int *)h->tables.p + n;
+	bool wide = frames % 4 == 0 && (uintptr_t)dev % 4 == 0 && (uintptr_t)tmp % 4 == 0;
+	size_t cols = wide ? frames / 4 : frames, blocks = (size_t)K * ((cols + 255) / 256);
+	if (blocks > 0x7FFFFFFFu)
+		return fail(POLAR_E_ARG, "polar_hip_systematic_extract: too many frames for one call");
+	if (wide)
+		hipLaunchKernelGGL(gather_rows_kernel<u32>, dim3((unsigned)blocks), dim3(256), 0, h->stream, (u32 *)dev, (const u32 *)tmp, info_pos, cols);
+	else
+		hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, h->stream, (uint8_t *)dev, (const uint8_t *)tmp, info_pos, cols);
+	HIP_TRY(hipGetLastError());
+	return POLAR_OK;
+}
+
 extern "C" int polar_hip_systematic_extract(polar_hip_handle *h, int8_t *decoded, const uint8_t *frozen, int level, size_t frames, int where)
 {
 	if (!h || !frozen || level < 1 || level > MAX_LEVEL || (where != POLAR_HOST && where != POLAR_DEVICE))
@@ -774,18 +837,8 @@ extern "C" int polar_hip_systematic_extract(polar_hip_handle *h, int8_t *decoded
 		dev = (int8_t *)h->stage_out.p;
 		HIP_TRY(hipMemcpyAsync(dev, decoded, (size_t)K * frames, hipMemcpyHostToDevice, h->stream));
 	}
-	if ((rc = encode_device(h, 0, (int8_t *)h->enc_tmp.p, dev, level, frames)))
+	if ((rc = extract_device(h, dev, (int8_t *)h->enc_tmp.p, level, K, frames)))
 		return rc;
-	const int *info_pos = (const int *)h->tables.p + n;
-	bool wide = frames % 4 == 0 && (uintptr_t)dev % 4 == 0;
-	size_t cols = wide ? frames / 4 : frames, blocks = (size_t)K * ((cols + 255) / 256);
-	if (blocks > 0x7FFFFFFFu)
-		return fail(POLAR_E_ARG, "polar_hip_systematic_extract: too many frames for one call");
-	if (wide)
-		hipLaunchKernelGGL(gather_rows_kernel<u32>, dim3((unsigned)blocks), dim3(256), 0, h->stream, (u32 *)dev, (const u32 *)h->enc_tmp.p, info_pos, cols);
-	else
-		hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, h->stream, (uint8_t *)dev, (const uint8_t *)h->enc_tmp.p, info_pos, cols);
-	HIP_TRY(hipGetLastError());
 	if (where == POLAR_HOST)
 		HIP_TRY(hipMemcpyAsync(decoded, dev, (size_t)K * frames, hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(hipStreamSynchronize(h->stream));
@@ -793,6 +846,15 @@ extern "C" int polar_hip_systematic_extract(polar_hip_handle *h, int8_t *decoded
 }
 
 // ---- bench counters ----
+
+static int count_device(polar_hip_handle *h, unsigned long long *c, const uint8_t *noisy, const uint8_t *orig, size_t n_code, const uint8_t *decoded, const uint8_t *message, size_t n_mesg)
+{
+	size_t work = (n_code > n_mesg ? n_code : n_mesg) / 16 / 256 + 1;
+	unsigned blocks = (unsigned)(work < (size_t)h->cus * 8 ? work : (size_t)h->cus * 8);
+	hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(256), 0, h->stream, c, noisy, orig, n_code, decoded, message, n_mesg);
+	HIP_TRY(hipGetLastError());
+	return POLAR_OK;
+}
 
 extern "C" int polar_hip_count(polar_hip_handle *h, int64_t *counters, const int8_t *noisy, const int8_t *orig, size_t n_code, const int8_t *decoded, const int8_t *message, size_t n_mesg, int where)
 {
@@ -819,15 +881,137 @@ extern "C" int polar_hip_count(polar_hip_handle *h, int64_t *counters, const int
 		c = (unsigned long long *)h->counters.p;
 		HIP_TRY(hipMemsetAsync(c, 0, 32, h->stream));
 	}
-	size_t work = (n_code > n_mesg ? n_code : n_mesg) / 16 / 256 + 1;
-	unsigned blocks = (unsigned)(work < (size_t)h->cus * 8 ? work : (size_t)h->cus * 8);
-	hipLaunchKernelGGL(count_kernel, dim3(blocks), dim3(256), 0, h->stream, c, p[0], p[1], n_code, p[2], p[3], n_mesg);
-	HIP_TRY(hipGetLastError());
+	if ((rc = count_device(h, c, p[0], p[1], n_code, p[2], p[3], n_mesg)))
+		return rc;
 	if (where == POLAR_HOST) {
 		int64_t tmp[4];
 		HIP_TRY(hipMemcpyAsync(tmp, c, 32, hipMemcpyDeviceToHost, h->stream));
 		HIP_TRY(hipStreamSynchronize(h->stream));
 		for (int k = 0; k < 4; ++k)
+			counters[k] += tmp[k];
+		return POLAR_OK;
+	}
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return POLAR_OK;
+}
+
+// ---- message source, channel, and the whole bench loop on the device ----
+
+static int launch_channel(polar_hip_handle *h, int mode, int8_t *out, const int8_t *cw, size_t rows, size_t frames, double snr_db, uint64_t seed, uint64_t frame0)
+{
+	double sigma = channel_sigma(snr_db), fact = 2.0 / (sigma * sigma);
+	size_t items = rows * (((frame0 + frames - 1) >> 2) - (frame0 >> 2) + 1);
+	size_t want = (items + 255) / 256, cap = (size_t)h->cus * 32;
+	unsigned blocks = (unsigned)(want < cap ? want : cap);
+	if (mode)
+		hipLaunchKernelGGL(channel_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, out, cw, rows, frames, sigma, fact, seed, frame0);
+	else
+		hipLaunchKernelGGL(channel_kernel<0>, dim3(blocks), dim3(256), 0, h->stream, out, cw, rows, frames, sigma, fact, seed, frame0);
+	HIP_TRY(hipGetLastError());
+	return POLAR_OK;
+}
+
+static int channel_entry(polar_hip_handle *h, int mode, int8_t *out, const int8_t *cw, size_t rows, size_t frames, double snr_db, uint64_t seed, uint64_t frame0, int where, const char *who)
+{
+	if (!h || (where != POLAR_HOST && where != POLAR_DEVICE) || rows > 0xFFFFFFFFu || (rows && frames && (!out || (!mode && !cw))))
+		return fail(POLAR_E_ARG, who);
+	int rc = use_device(h);
+	if (rc)
+		return rc;
+	if (!rows || !frames)
+		return POLAR_OK;
+	size_t bytes = rows * frames;
+	if (where == POLAR_DEVICE) {
+		if ((rc = launch_channel(h, mode, out, cw, rows, frames, snr_db, seed, frame0)))
+			return rc;
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		return POLAR_OK;
+	}
+	if ((rc = h->stage_in.reserve(bytes)) || (rc = h->stage_out.reserve(bytes)))
+		return rc;
+	if (!mode)
+		HIP_TRY(hipMemcpyAsync(h->stage_in.p, cw, bytes, hipMemcpyHostToDevice, h->stream));
+	if ((rc = launch_channel(h, mode, (int8_t *)h->stage_out.p, (const int8_t *)h->stage_in.p, rows, frames, snr_db, seed, frame0)))
+		return rc;
+	HIP_TRY(hipMemcpyAsync(out, h->stage_out.p, bytes, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return POLAR_OK;
+}
+
+extern "C" int polar_hip_random_message(polar_hip_handle *h, int8_t *message, size_t rows, size_t frames, uint64_t seed, uint64_t first_frame, int where)
+{
+	return channel_entry(h, 1, message, nullptr, rows, frames, 0.0, seed, first_frame, where, "polar_hip_random_message: bad argument");
+}
+
+extern "C" int polar_hip_channel(polar_hip_handle *h, int8_t *llr, const int8_t *codeword, size_t rows, size_t frames, double snr_db, uint64_t seed, uint64_t first_frame, int where)
+{
+	return channel_entry(h, 0, llr, codeword, rows, frames, snr_db, seed, first_frame, where, "polar_hip_channel: bad argument");
+}
+
+extern "C" int polar_hip_simulate(polar_hip_handle *h, int program_id, const uint8_t *frozen, int level, int systematic, double snr_db, uint64_t seed, uint64_t first_frame, size_t frames, int64_t *counters, int where)
+{
+	if (!h || !frozen || !counters || level < 1 || level > MAX_LEVEL || (where != POLAR_HOST && where != POLAR_DEVICE))
+		return fail(POLAR_E_ARG, "polar_hip_simulate: bad argument");
+	if (program_id < 0 || (size_t)program_id >= h->programs.size() || h->programs[program_id].host.top != level)
+		return fail(POLAR_E_ARG, "polar_hip_simulate: program id unknown or not of this level");
+	int rc = use_device(h), K = 0;
+	if (rc)
+		return rc;
+	if ((rc = upload_tables(h, frozen, level, &K)))
+		return rc;
+	if ((uint32_t)K != h->programs[program_id].host.rows)
+		return fail(POLAR_E_PROGRAM, "polar_hip_simulate: program and frozen set disagree on K");
+	const size_t n = (size_t)1 << level;
+	if ((rc = h->counters.reserve(64)))
+		return rc;
+	unsigned long long *c = where == POLAR_DEVICE ? (unsigned long long *)counters : (unsigned long long *)h->counters.p;
+	if (where == POLAR_HOST)
+		HIP_TRY(hipMemsetAsync(c, 0, 48, h->stream));
+	// chunk: whole 1024-frame blocks within a quarter of the free memory (and at most 64 GiB)
+	size_t free_b = 0, total_b = 0;
+	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+	size_t held = h->sim_cw.bytes + h->sim_llr.bytes + h->sim_msg.bytes + h->sim_dec.bytes;
+	size_t budget = held + free_b / 4;
+	if (budget > ((size_t)64 << 30))
+		budget = (size_t)64 << 30;
+	size_t per_frame = 2 * n + 2 * (size_t)(K ? K : 1);
+	size_t chunk = budget / per_frame;
+	if (chunk >= 1024)
+		chunk -= chunk % 1024;
+	if (chunk < 1)
+		return fail(POLAR_E_NOMEM, "polar_hip_simulate: not enough device memory for one frame");
+	if (chunk > frames)
+		chunk = frames;
+	if (frames) {
+		if ((rc = h->sim_cw.reserve(n * chunk)) || (rc = h->sim_llr.reserve(n * chunk)) || (rc = h->sim_msg.reserve((size_t)(K ? K : 1) * chunk)) || (rc = h->sim_dec.reserve((size_t)(K ? K : 1) * chunk)))
+			return rc;
+	}
+	int8_t *cw = (int8_t *)h->sim_cw.p, *llr = (int8_t *)h->sim_llr.p, *msg = (int8_t *)h->sim_msg.p, *dec = (int8_t *)h->sim_dec.p;
+	for (size_t a = 0; a < frames; a += chunk) {
+		size_t f = frames - a < chunk ? frames - a : chunk;
+		uint64_t f0 = first_frame + a;
+		if (K && (rc = launch_channel(h, 1, msg, nullptr, (size_t)K, f, 0.0, seed, f0)))
+			return rc;
+		if ((rc = encode_device(h, systematic, cw, msg, level, f)))
+			return rc;
+		if ((rc = launch_channel(h, 0, llr, cw, n, f, snr_db, seed, f0)))
+			return rc;
+		if ((rc = count_device(h, c, (const uint8_t *)llr, (const uint8_t *)cw, n * f, nullptr, nullptr, 0)))
+			return rc;
+		if ((rc = launch_decode(h, program_id, dec, llr, f, h->stream, false)))
+			return rc;
+		if (systematic && K && (rc = extract_device(h, dec, cw, level, K, f)))
+			return rc;
+		if (K && (rc = count_device(h, c, nullptr, nullptr, 0, (const uint8_t *)dec, (const uint8_t *)msg, (size_t)K * f)))
+			return rc;
+	}
+	hipLaunchKernelGGL(add_counters_kernel, dim3(1), dim3(1), 0, h->stream, c, (unsigned long long)frames, (unsigned long long)frames * (unsigned long long)K);
+	HIP_TRY(hipGetLastError());
+	if (where == POLAR_HOST) {
+		int64_t tmp[6];
+		HIP_TRY(hipMemcpyAsync(tmp, c, 48, hipMemcpyDeviceToHost, h->stream));
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		for (int k = 0; k < 6; ++k)
 			counters[k] += tmp[k];
 		return POLAR_OK;
 	}

@@ -108,6 +108,22 @@ class Oracle:
         self.L.oracle_count(_ptr(c), _ptr(noisy), _ptr(orig), noisy.size, _ptr(decoded), _ptr(message), decoded.size)
         return c
 
+    def philox(self, counter, key):
+        out = (ctypes.c_uint32 * 4)()
+        self.L.oracle_philox4x32_10(out, (ctypes.c_uint32 * 4)(*counter), (ctypes.c_uint32 * 2)(*key))
+        return list(out)
+
+    def random_message(self, rows, frames, seed, first_frame=0):
+        out = np.zeros((rows, frames), np.int8)
+        self.L.oracle_random_message(_ptr(out), ctypes.c_size_t(rows), ctypes.c_size_t(frames), ctypes.c_uint64(seed), ctypes.c_uint64(first_frame))
+        return out
+
+    def channel(self, codeword, snr_db, seed, first_frame=0):
+        codeword = _c(codeword, np.int8)
+        out = np.zeros_like(codeword)
+        self.L.oracle_channel(_ptr(out), _ptr(codeword), ctypes.c_size_t(codeword.shape[0]), ctypes.c_size_t(codeword.shape[1]), ctypes.c_double(snr_db), ctypes.c_uint64(seed), ctypes.c_uint64(first_frame))
+        return out
+
     def quant(self, x):
         return np.array([self.L.oracle_quant(float(v)) for v in np.ravel(x)], np.int8).reshape(np.shape(x))
 

@@ -238,6 +238,65 @@ def test_counters(session, oracle):
         assert d.cpu().tolist() == exp.tolist()
 
 
+def test_channel_and_message_vs_oracle(session, oracle):
+    """polar_hip_random_message / polar_hip_channel against the CPU restatement. The message bits
+    are integer work: exact. The channel goes through double log / sqrt / sin / cos on both sides;
+    a last-place difference there can move a sample across a rounding boundary of quant(), so
+    the stated tolerance is: at most 1 in 10^5 LLRs differing, and by no more than 1."""
+    rows = 96
+    for frames, first in ((257, 0), (64, 4), (130, 1001), (3, 2)):
+        got = np.zeros((rows, frames), np.int8)
+        session.random_message(got, 11, first)
+        assert (got == oracle.random_message(rows, frames, 11, first)).all(), (frames, first)
+        cw = got  # any +-1 array
+        for snr in (-3.0, -1.0, 4.0, 30.0):
+            llr = np.zeros_like(cw)
+            session.channel(llr, cw, snr, 5, first)
+            exp = oracle.channel(cw, snr, 5, first)
+            diff = llr.astype(int) - exp.astype(int)
+            assert np.abs(diff).max() <= 1 and (diff != 0).mean() <= 1e-5, (frames, first, snr)
+    # device buffers, sharded generation equals the whole batch
+    d_cw = torch.from_numpy(oracle.random_message(rows, 4096, 3)).cuda()
+    whole = torch.zeros_like(d_cw)
+    session.channel(whole, d_cw, -1.0, 8, 0)
+    parts = []
+    for a, b in ((0, 1000), (1000, 1003), (1003, 4096)):
+        part = torch.zeros((rows, b - a), dtype=torch.int8, device="cuda")
+        session.channel(part, d_cw[:, a:b].contiguous(), -1.0, 8, a)
+        parts.append(part)
+    assert bool((torch.cat(parts, dim=1) == whole).all())
+
+
+def test_simulate_matches_the_step_by_step_chain(session, oracle):
+    """polar_hip_simulate (testbench.cc:125-193 on the device) against the same chain assembled
+    from the oracle's pieces on the device-generated LLRs, both encoders, sharded and whole."""
+    import polar_amd
+
+    for M, frames, systematic, snr in ((8, 300, 0, 1.0), (10, 1100, 1, -1.0), (12, 260, 1, -3.0)):
+        N = 1 << M
+        fro = _code(oracle, M)
+        prog = oracle.compile(fro, M)
+        K = N // 2
+        seed, first = 77 + M, 40
+        got = np.zeros(6, np.int64)
+        session.simulate(got, prog, fro, M, systematic, snr, seed, first, frames)
+        msg = oracle.random_message(K, frames, seed, first)
+        cw = oracle.encode(msg, fro, M, systematic)
+        llr = np.zeros_like(cw)
+        session.channel(llr, cw, snr, seed, first)  # the device's own LLRs (see the tolerance above)
+        dec = oracle.decode(llr, prog)
+        if systematic:
+            dec = oracle.systematic_extract(dec, fro, M)
+        exp = oracle.count(llr, cw, dec, msg)
+        assert got[:4].tolist() == list(exp), (M, got, exp)
+        assert got[4] == frames and got[5] == frames * K
+        # two shards into a device counter array add up to the same totals
+        d = torch.zeros(6, dtype=torch.int64, device="cuda")
+        session.simulate(d, prog, fro, M, systematic, snr, seed, first, 100)
+        session.simulate(d, prog, fro, M, systematic, snr, seed, first + 100, frames - 100)
+        assert d.cpu().numpy().tolist() == got.tolist()
+
+
 def test_cpp_dropin_header():
     """include/polar_amd/polar.hh: the reference bench's call sequence with TYPE = GPU<int8_t, W>
     (tests/cpp/dropin_test.cc, built by __graft_entry__.build())."""

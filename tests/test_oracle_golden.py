@@ -134,3 +134,33 @@ def test_systematic_round_trip_and_counters(oracle):
     llr2[1, :] = -llr2[1, :]
     c = oracle.count(llr2, cw, dec, msg)
     assert c.tolist() == [F, F, 0, 0]
+
+
+def test_philox_known_answers(oracle):
+    """Philox-4x32-10 known-answer vectors of Random123 (kat_vectors: philox4x32 10)."""
+    assert oracle.philox([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert oracle.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert oracle.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_channel_restatement_properties(oracle):
+    """testbench.cc:112-114, 151-165: the channel is a pure function of (seed, row, global frame),
+    its noise has the bench's sigma, and quantisation follows polar_helper.hh:194-198."""
+    rows, frames = 64, 1000
+    cw = np.ones((rows, frames), np.int8)
+    a = oracle.channel(cw, 30.0, 7)  # sigma = 0.022: llr = round(2/sigma^2 * y) saturates
+    assert (a == 127).all()
+    snr = 3.0
+    sigma = np.sqrt(1.0 / (2.0 * 10.0 ** (snr / 10.0)))
+    llr = oracle.channel(cw, snr, 7).astype(np.float64)
+    assert np.abs(llr).max() < 127  # not saturated at this SNR
+    y = llr * sigma * sigma / 2.0
+    assert abs(y.mean() - 1.0) < 4 * sigma / np.sqrt(y.size) + 0.01
+    assert abs(y.std() - sigma) < 0.01
+    # sharding: frames [300, 700) generated alone equal the slice of the whole batch
+    part = oracle.channel(cw[:, 300:700], snr, 7, first_frame=300)
+    assert (part == oracle.channel(cw, snr, 7)[:, 300:700]).all()
+    m = oracle.random_message(32, 4000, 9)
+    assert set(np.unique(m)) == {-1, 1} and abs(m.mean()) < 0.02
+    assert (oracle.random_message(32, 100, 9, first_frame=1001) == oracle.random_message(32, 4000, 9)[:, 1001:1101]).all()
+    assert (oracle.random_message(32, 100, 10) != m[:, :100]).any()
