@@ -482,7 +482,32 @@ static size_t scratch_bytes_per_wave(int q, int top)
 // Default shape: the ~20 KB-of-LDS family (7 wavefronts per CU), widest first. 128 frames per
 // wavefront measured best at N = 2^16; narrower groups when the batch is too small
 // to give every resident wavefront a group, or when the scratch arenas would not fit.
-static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, size_t frames, size_t scratch_cap)
+// Scratch budget: what the handle holds already plus half of the free device memory. The query
+// is slow (milliseconds), so it is made only when a request exceeds what is held.
+struct ScratchBudget {
+	const polar_hip_handle *h;
+	size_t cap = 0;
+	bool queried = false;
+	bool fits(size_t bytes)
+	{
+		if (bytes <= h->scratch.bytes)
+			return true;
+		return bytes <= limit();
+	}
+	size_t limit()
+	{
+		if (!queried) {
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
+				free_b = 0;
+			cap = h->scratch.bytes + free_b / 2;
+			queried = true;
+		}
+		return cap;
+	}
+};
+
+static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, size_t frames, ScratchBudget &budget)
 {
 	if (h->cfg_frames_per_wave)
 		return find_variant(h->cfg_frames_per_wave / 4, h->cfg_lds_level);
@@ -492,7 +517,7 @@ static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, siz
 		size_t groups = (frames + 4 * f[0] - 1) / (4 * f[0]);
 		if (f[0] > 1 && groups < resident)
 			continue;
-		if (f[0] > 1 && top > f[1] && resident * scratch_bytes_per_wave(f[0], top) > scratch_cap)
+		if (f[0] > 1 && top > f[1] && !budget.fits(resident * scratch_bytes_per_wave(f[0], top)))
 			continue;
 		return find_variant(f[0], f[1]);
 	}
@@ -505,10 +530,8 @@ static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, siz
 static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, hipStream_t stream, bool timed)
 {
 	LoadedProgram &lp = h->programs[program_id];
-	size_t free_b = 0, total_b = 0;
-	HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-	const size_t scratch_cap = h->scratch.bytes + free_b / 2; // what is held already plus half of what is left
-	const KernelVariant *v = pick_variant(h, lp.host.top, frames, scratch_cap);
+	ScratchBudget budget{h};
+	const KernelVariant *v = pick_variant(h, lp.host.top, frames, budget);
 	if (!v)
 		return fail(POLAR_E_ARG, "no kernel variant for the configured (frames_per_wave, lds_level)");
 	if (!lp.dev.count(v->q)) { // first use with this wavefront shape: fuse and upload
@@ -548,21 +571,23 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	size_t blocks = (size_t)per_cu * h->cus;
 	if (h->cfg_max_waves && (size_t)h->cfg_max_waves < blocks)
 		blocks = h->cfg_max_waves;
-	size_t block_dwords = 0;
+	size_t block_dwords = 0, max_blocks = ~(size_t)0 >> 8;
 	if (lp.host.top > v->rl) { // LLR levels above the LDS levels and the partial-sum planes live in scratch
 		size_t soft = (size_t)v->q << lp.host.top;
 		block_dwords = soft + 2 * (soft / 8);
-		const size_t fit = scratch_cap / (block_dwords * sizeof(u32));
-		if (fit < 1)
-			return fail(POLAR_E_NOMEM, "not enough device memory for one wavefront's scratch arena");
-		if (blocks > fit) // fewer resident wavefronts, more sweeps
-			blocks = fit;
+		if (!budget.fits(blocks * block_dwords * sizeof(u32))) { // fewer resident wavefronts, more sweeps
+			max_blocks = budget.limit() / (block_dwords * sizeof(u32));
+			if (max_blocks < 1)
+				return fail(POLAR_E_NOMEM, "not enough device memory for one wavefront's scratch arena");
+			if (blocks > max_blocks)
+				blocks = max_blocks;
+		}
 	}
 	// every wavefront walks the same number of groups: no idle tail behind a last partial sweep
 	size_t sweeps = (groups + blocks - 1) / blocks;
 	blocks = (groups + sweeps - 1) / sweeps;
 	if (blocks >= 8 && blocks % 8) // multiple of 8 for the XCD-aware group order
-		blocks = blocks + 8 - blocks % 8 <= (block_dwords ? scratch_cap / (block_dwords * sizeof(u32)) : blocks + 8) ? blocks + 8 - blocks % 8 : blocks - blocks % 8;
+		blocks = blocks + 8 - blocks % 8 <= max_blocks ? blocks + 8 - blocks % 8 : blocks - blocks % 8;
 	if (getenv("POLAR_HIP_DEBUG"))
 		fprintf(stderr, "polar_hip: decode Q=%d RL=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d\n", v->q, v->rl, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct);
 	DecodeArgs a;

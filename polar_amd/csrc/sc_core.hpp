@@ -201,12 +201,24 @@ PDEV u32x4 qadd4(u32x4 a, u32x4 b) { u32x4 r; r.x = qadd4(a.x, b.x); r.y = qadd4
 
 // ---- memory views ----
 
+// Scratch vectors and input rows are streamed: written once, read once or twice much later by
+// the same wavefront, far beyond what L2 or the Infinity Cache can hold in between. Marking the
+// 16-byte accesses non-temporal keeps them from evicting lines that do get reused (+8 % at
+// N = 2^16). POLAR_NO_NT restores default-policy accesses for comparison.
 struct GVec { // linear dword array in the HBM scratch arena
 	u32 *p;
 	PDEV u32 ld(int t) const { return p[t]; }
 	PDEV void st(int t, u32 v) const { p[t] = v; }
+#if !defined(POLAR_EMU) && !defined(POLAR_NO_NT)
+	PDEV u32x4 ld4(int t) const { return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + t)); }
+#else
 	PDEV u32x4 ld4(int t) const { return *reinterpret_cast<const u32x4 *>(p + t); }
+#endif
+#if !defined(POLAR_EMU) && !defined(POLAR_NO_NT)
+	PDEV void st4(int t, u32x4 v) const { __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p + t)); }
+#else
 	PDEV void st4(int t, u32x4 v) const { *reinterpret_cast<u32x4 *>(p + t) = v; }
+#endif
 };
 
 struct LVec { // linear dword array in LDS
@@ -232,7 +244,7 @@ template <int Q> struct InVec {
 	{
 		if (Q % 4 == 0) { // four consecutive quads of one row: rows are 16-byte aligned then
 			int i = t / Q, q = t % Q;
-#if defined(POLAR_NT_INPUT) && !defined(POLAR_EMU)
+#if !defined(POLAR_EMU) && !defined(POLAR_NO_NT)
 			return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + (size_t)i * stride + 4 * q));
 #else
 			return *reinterpret_cast<const u32x4 *>(p + (size_t)i * stride + 4 * q);
@@ -263,6 +275,16 @@ PDEV void stp4(u32 *p, u32x4 v) { *reinterpret_cast<u32x4 *>(p) = v; }
 #ifndef POLAR_EMU
 PDEV u32x4 ldp4(const lds_u32 *p) { return *reinterpret_cast<const lds_u32x4 *>(p); }
 PDEV void stp4(lds_u32 *p, u32x4 v) { *reinterpret_cast<lds_u32x4 *>(p) = v; }
+#endif
+// streaming (non-temporal) forms for the long plane arrays in scratch; plain for LDS
+#if !defined(POLAR_EMU) && !defined(POLAR_NO_NT)
+PDEV u32x4 ldp4s(const u32 *p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p)); }
+PDEV void stp4s(u32 *p, u32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p)); }
+PDEV u32x4 ldp4s(const lds_u32 *p) { return ldp4(p); }
+PDEV void stp4s(lds_u32 *p, u32x4 v) { stp4(p, v); }
+#else
+template <class T> PDEV u32x4 ldp4s(const T *p) { return ldp4(p); }
+template <class T> PDEV void stp4s(T *p, u32x4 v) { stp4(p, v); }
 #endif
 
 template <class A> struct SrcIsLds { static const bool value = false; };
@@ -599,9 +621,9 @@ struct Group {
 						int t = t0 + 256 * u;
 						if (t < n) {
 							if (MODE != 3)
-								y[u] = ldp4(b + t);
+								y[u] = ldp4s(b + t);
 							if (MODE == 1 || MODE == 2)
-								x[u] = ldp4(a + t);
+								x[u] = ldp4s(a + t);
 						}
 					}
 #pragma unroll
@@ -619,7 +641,7 @@ struct Group {
 								r.x = x[u].x | y[u].x; r.y = x[u].y | y[u].y; r.z = x[u].z | y[u].z; r.w = x[u].w | y[u].w;
 							}
 							acc |= r.x | r.y | r.z | r.w;
-							stp4(d + t, r);
+							stp4s(d + t, r);
 						}
 					}
 				}
