@@ -297,6 +297,32 @@ def test_simulate_matches_the_step_by_step_chain(session, oracle):
         assert d.cpu().numpy().tolist() == got.tolist()
 
 
+def test_mixed_sizes_in_one_launch_set(session, oracle):
+    """BASELINE config E: codes of N = 2^10 .. 2^16, each with its own design SNR (its own frozen
+    set and program), resident together and decoded back to back on one stream without a host
+    synchronisation in between."""
+    import polar_amd
+
+    dec = polar_amd.PolarDecoder(session)
+    stream = torch.cuda.Stream()
+    jobs = []
+    for k, M in enumerate(range(10, 17)):
+        N = 1 << M
+        p = float(np.exp(-(10.0 ** ((-2.0 + 0.5 * k) / 10.0))))  # design point moves with the code, testbench.cc:74-88
+        fro, _ = oracle.const0(M, N // 2, p)
+        prog = oracle.compile(fro, M)
+        frames = 24 + 13 * k
+        msg = oracle.random_message(N // 2, frames, 100 + M)
+        llr = oracle.channel(oracle.encode(msg, fro, M, 1), 0.0, 200 + M)
+        jobs.append((prog, llr, torch.from_numpy(llr).cuda(), torch.zeros((N // 2, frames), dtype=torch.int8, device="cuda")))
+    torch.cuda.synchronize()
+    for prog, _llr, d_llr, d_out in jobs:
+        dec.launch(d_out, d_llr, prog, stream.cuda_stream)
+    stream.synchronize()
+    for prog, llr, _d, d_out in jobs:
+        assert (d_out.cpu().numpy() == oracle.decode(llr, prog)).all(), int(prog[0])
+
+
 def test_cpp_dropin_header():
     """include/polar_amd/polar.hh: the reference bench's call sequence with TYPE = GPU<int8_t, W>
     (tests/cpp/dropin_test.cc, built by __graft_entry__.build())."""
