@@ -72,7 +72,6 @@ __global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
 	g.sl = (lds_u32 *)lds;
 	g.hls = g.sl + G::LDS_SOFT;
 	g.hlz = g.hls + G::LDS_PLANE;
-	g.tl = g.hlz + G::LDS_PLANE;
 	g.sg = arena;
 	g.hgs = arena ? arena + ((size_t)Q << a.top) : nullptr;
 	g.hgz = arena ? g.hgs + plane : nullptr;
@@ -479,7 +478,7 @@ static size_t scratch_bytes_per_wave(int q, int top)
 	return (soft + 2 * (soft / 8)) * sizeof(u32);
 }
 
-// Default shape: the ~20 KB-of-LDS family (7 wavefronts per CU), widest first. 128 frames per
+// Default shape: the 20 KiB-of-LDS family (8 wavefronts per CU), widest first. 128 frames per
 // wavefront measured best at N = 2^16; narrower groups when the batch is too small
 // to give every resident wavefront a group, or when the scratch arenas would not fit.
 // Scratch budget: what the handle holds already plus half of the free device memory. The query
@@ -511,7 +510,7 @@ static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, siz
 {
 	if (h->cfg_frames_per_wave)
 		return find_variant(h->cfg_frames_per_wave / 4, h->cfg_lds_level);
-	const size_t resident = (size_t)7 * h->cus;
+	const size_t resident = (size_t)8 * h->cus;
 	static const int family[][2] = {{32, 6}, {16, 7}, {8, 8}, {4, 9}, {2, 10}, {1, 11}};
 	for (const auto &f : family) {
 		size_t groups = (frames + 4 * f[0] - 1) / (4 * f[0]);

@@ -325,11 +325,10 @@ template <int Q, int RL>
 struct Group {
 	static_assert(RL >= 4, "nodes that share a partial-sum octet must live in LDS");
 	static const int W = 1 << (RL + 1); // elements of the LDS partial-sum window
-	static const int LDS_SOFT = Q << (RL + 1), LDS_PLANE = (W / 8) * Q, LDS_TMP = 8 * Q;
-	static const int LDS_DWORDS = LDS_SOFT + 2 * LDS_PLANE + LDS_TMP;
+	static const int LDS_SOFT = Q << (RL + 1), LDS_PLANE = (W / 8) * Q;
+	static const int LDS_DWORDS = LDS_SOFT + 2 * LDS_PLANE; // (128, 6): exactly 20 KiB, 8 wavefronts per CU
 	lds_u32 *sl;        // LDS soft arena, LDS_SOFT dwords (level l at Q << l)
 	lds_u32 *hls, *hlz; // LDS partial-sum planes (sign, zero), LDS_PLANE dwords each, index by position mod W
-	lds_u32 *tl;        // LDS scratch, LDS_TMP dwords
 	u32 *sg;            // scratch soft arena, Q << top dwords
 	u32 *hgs, *hgz;     // scratch partial-sum planes, (Q << top) / 8 dwords each
 	InVec<Q> in;
@@ -958,7 +957,7 @@ struct Group {
 			}
 		}
 		wave_sync();
-		lds_u32 *wk = tl; // per quad: weakest magnitude (2 dwords) and odd-parity mask
+		lds_u32 *wk = sl + Q; // per quad: weakest magnitude (2 dwords) and odd-parity mask, in the dead levels 0-1
 		PFOR_LANES(lane) {
 			if (lane < Q) {
 				u32 mh = 0x7F007F00u, ml = 0x7F007F00u, px = 0;
@@ -1001,8 +1000,8 @@ struct Group {
 
 	// spc (polar_decoder.hh:107-127) for nodes of >= 256 plane dwords: every lane owns four frame
 	// quads of every (256/Q)-th octet, keeps the running weakest magnitude and parity in registers
-	// and has its eight 16-byte loads in flight together. red: 768 dwords of LDS.
-	static const bool WIDE_LEAVES = Q % 4 == 0 && LDS_SOFT >= Q + 768;
+	// and has its eight 16-byte loads in flight together. red: 768 + 3Q dwords of (dead) LDS.
+	static const bool WIDE_LEAVES = Q % 4 == 0 && LDS_SOFT >= 4 * Q + 768;
 	template <class SRC, class T>
 	PDEV void spc_wide(int lvl, const SRC &src, Planes<T> p, T *tmp, lds_u32 *red, u32 row, bool wz)
 	{
@@ -1048,7 +1047,7 @@ struct Group {
 			}
 		}
 		wave_sync();
-		lds_u32 *wk = tl; // per quad: weakest magnitude (two arrays) and odd-parity mask
+		lds_u32 *wk = red + 768; // per quad: weakest magnitude (two arrays) and odd-parity mask
 		PFOR_LANES(lane) {
 			if (lane < Q) {
 				u32 mh = 0x7F007F00u, ml = 0x7F007F00u, px = 0;

@@ -86,7 +86,6 @@ static int run(int8_t *msg, const int8_t *cw, const HostProgram &hp, size_t fram
 		g.sl = lds.data();
 		g.hls = g.sl + G::LDS_SOFT;
 		g.hlz = g.hls + G::LDS_PLANE;
-		g.tl = g.hlz + G::LDS_PLANE;
 		g.sg = soft.data();
 		g.hgs = planes.data();
 		g.hgz = planes.data() + nsoft / 8;

@@ -26,7 +26,7 @@ import polar_amd
 N = 1 << a.M
 if a.sweeps:
     q = a.fpw // 4
-    lds = 4 * ((q << (a.lds_level + 1)) * 5 // 4 + 8 * q)
+    lds = 4 * ((q << (a.lds_level + 1)) * 5 // 4)
     per_cu = min(16, 163840 // lds)
     a.frames = int(a.sweeps * per_cu * 256 * a.fpw)
 fro = np.zeros(N, np.uint8)
