@@ -59,6 +59,8 @@ struct DecodeArgs {
 // Persistent wavefronts: block b walks the groups b, b + gridDim, ... Blocks are dealt to
 // the 8 XCDs round-robin, so within one sweep the blocks that share an XCD (equal b % 8) take
 // neighbouring groups: those groups share the 128-byte lines of every input row.
+// 128 VGPRs for every variant: with more (tried: 180 for the 8-per-CU variants) the wavefronts of a
+// CU no longer fit unless they spread evenly over the SIMDs, and the kernel ran 15 % slower.
 template <int Q, int RL>
 __global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
 {

@@ -815,38 +815,70 @@ struct Group {
 		wave_sync();
 	}
 
+	// one or two butterfly stages (octet distance ho, and 2*ho when TWO) of the transform on one
+	// plane array of noct*Q dwords; OR instead of XOR for the zero plane
+	template <bool TWO, bool IS_OR, class E, class T>
+	PDEV void trans_stage(T *w, int n, int ho, int lane_step)
+	{
+		const int per = TWO ? 4 : 2, V = sizeof(E) / 4;
+		PFOR_LANES(lane) {
+			for (int t = lane * V; t < n / per; t += lane_step) {
+				int o = t / Q, q = t % Q;
+				int i0 = ((o / ho) * per * ho + (o % ho)) * Q + q, d = ho * Q;
+				E x0 = ldE_p(w + i0, E()), x1 = ldE_p(w + i0 + d, E());
+				if (TWO) {
+					E x2 = ldE_p(w + i0 + 2 * d, E()), x3 = ldE_p(w + i0 + 3 * d, E());
+					x0 = IS_OR ? (x0 | x1) | (x2 | x3) : (x0 ^ x1) ^ (x2 ^ x3);
+					x1 = IS_OR ? x1 | x3 : x1 ^ x3;
+					x2 = IS_OR ? x2 | x3 : x2 ^ x3;
+					stE_p(w + i0 + d, x1);
+					stE_p(w + i0 + 2 * d, x2);
+				} else {
+					x0 = IS_OR ? x0 | x1 : x0 ^ x1;
+				}
+				stE_p(w + i0, x0);
+			}
+		}
+	}
+	template <class T> static PDEV u32 ldE_p(const T *p, u32) { return *p; }
+	template <class T> static PDEV u32x4 ldE_p(const T *p, u32x4) { return ldp4(p); }
+	template <class T> static PDEV void stE_p(T *p, u32 v) { *p = v; }
+	template <class T> static PDEV void stE_p(T *p, u32x4 v) { stp4(p, v); }
+
 	// polar transform of a node's decisions (trans, polar_decoder.hh:15-27) on bit planes held in
 	// ts / tz (noct*Q dwords each, element 0 at bit 7), then emission of elements first..len-1
-	// as message rows row, row+1, ... (len >= 16)
+	// as message rows row, row+1, ... (len >= 16). hz: tz holds erasures; without it tz is
+	// neither read nor written. Two stages per pass where the node is deep enough.
 	template <class T>
-	PDEV void trans_emit(T *ts, T *tz, int len, int first, u32 row)
+	PDEV void trans_emit(T *ts, T *tz, int len, int first, u32 row, bool hz)
 	{
 		int noct = len >> 3;
 		int n = noct * Q;
-		for (int ho = 1; ho < noct; ho *= 2) { // stages h = 8*ho
-			if (Q % 4 == 0 && n >= 512) {
-				PFOR_LANES(lane) {
-					for (int t = lane * 4; t < n / 2; t += 256) {
-						int o = t / Q, q = t % Q;
-						int lo = ((o / ho) * 2 * ho + (o % ho)) * Q + q, hi = lo + ho * Q;
-						u32x4 a = ldp4(ts + lo), b = ldp4(ts + hi), c = ldp4(tz + lo), d = ldp4(tz + hi);
-						a.x ^= b.x; a.y ^= b.y; a.z ^= b.z; a.w ^= b.w;
-						c.x |= d.x; c.y |= d.y; c.z |= d.z; c.w |= d.w;
-						stp4(ts + lo, a);
-						stp4(tz + lo, c);
-					}
+		for (int ho = 1; ho < noct;) { // stages h = 8*ho
+			bool two = 4 * ho <= noct;
+			if (two) {
+				if (Q % 4 == 0 && n >= 1024) {
+					trans_stage<true, false, u32x4>(ts, n, ho, 256);
+					if (hz)
+						trans_stage<true, true, u32x4>(tz, n, ho, 256);
+				} else {
+					trans_stage<true, false, u32>(ts, n, ho, 64);
+					if (hz)
+						trans_stage<true, true, u32>(tz, n, ho, 64);
 				}
 			} else {
-				PFOR_LANES(lane) {
-					for (int t = lane; t < n / 2; t += 64) {
-						int o = t / Q, q = t % Q;
-						int lo = ((o / ho) * 2 * ho + (o % ho)) * Q + q, hi = lo + ho * Q;
-						ts[lo] ^= ts[hi];
-						tz[lo] |= tz[hi];
-					}
+				if (Q % 4 == 0 && n >= 512) {
+					trans_stage<false, false, u32x4>(ts, n, ho, 256);
+					if (hz)
+						trans_stage<false, true, u32x4>(tz, n, ho, 256);
+				} else {
+					trans_stage<false, false, u32>(ts, n, ho, 64);
+					if (hz)
+						trans_stage<false, true, u32>(tz, n, ho, 64);
 				}
 			}
 			wave_sync();
+			ho *= two ? 4 : 2;
 		}
 		int cnt = (len - first) * Q;
 		if (Q % 4 == 0) {
@@ -854,7 +886,11 @@ struct Group {
 				for (int t = lane * 4; t < cnt; t += 256) {
 					int e = first + t / Q, q = t % Q;
 					int i = pidx((u32)e, q), sh = e & 7;
-					u32x4 a = ldp4(ts + i), b = ldp4(tz + i), v;
+					u32x4 a = ldp4(ts + i), b, v;
+					if (hz)
+						b = ldp4(tz + i);
+					else
+						b.x = b.y = b.z = b.w = 0;
 					v.x = symbols(a.x << sh, b.x << sh);
 					v.y = symbols(a.y << sh, b.y << sh);
 					v.z = symbols(a.z << sh, b.z << sh);
@@ -867,7 +903,7 @@ struct Group {
 				for (int t = lane; t < cnt; t += 64) {
 					int e = first + t / Q, q = t % Q;
 					int i = pidx((u32)e, q), sh = e & 7;
-					out.st(row + (u32)(e - first), q, symbols(ts[i] << sh, tz[i] << sh));
+					out.st(row + (u32)(e - first), q, symbols(ts[i] << sh, hz ? tz[i] << sh : 0u));
 				}
 			}
 		}
@@ -932,7 +968,7 @@ struct Group {
 				any |= wave_any(acc);
 			}
 			wave_sync();
-			trans_emit(ts, tz, len, 0, row);
+			trans_emit(ts, tz, len, 0, row, any != 0);
 			return any;
 		}
 		// spc (polar_decoder.hh:107-127)
@@ -990,11 +1026,10 @@ struct Group {
 					p.z[i0 + t] = 0;
 				trans_octet(s, z, 8);
 				ts[t] = s;
-				tz[t] = 0;
 			}
 		}
 		wave_sync();
-		trans_emit(ts, tz, len, 1, row);
+		trans_emit(ts, tz, len, 1, row, false);
 		return 0; // a parity-check node never decides 0 (polar_decoder.hh:107-127)
 	}
 
@@ -1098,11 +1133,10 @@ struct Group {
 				}
 				sv.x = sg4[0]; sv.y = sg4[1]; sv.z = sg4[2]; sv.w = sg4[3];
 				stp4(ts + t, sv);
-				stp4(tz + t, zero);
 			}
 		}
 		wave_sync();
-		trans_emit(ts, tz, len, 1, row);
+		trans_emit(ts, tz, len, 1, row, false);
 	}
 
 	PDEV void leaf(u32 op, int lvl, u32 hrd, u32 row)
@@ -1139,8 +1173,9 @@ struct Group {
 		T *ts = tmp, *tz = tmp + n;
 		int j0 = (int)(o.eb & 7); // nonzero only when the whole node fits one octet
 		int il0 = pidx(c.eb, 0), ol0 = pidx(o.eb, 0), or0 = pidx(o.eb + h, 0);
+		u32 anyr = 0;
 		PFOR_LANES(lane) {
-			u32 acc = 0;
+			u32 acc = 0, accr = 0;
 			for (int t = lane; t < n; t += 64) {
 				int oc = t / Q, q = t % Q;
 				u32 ls = c.s[il0 + t], lz = fl ? c.z[il0 + t] : 0u;
@@ -1168,6 +1203,7 @@ struct Group {
 					o.z[ol0 + t] = z;
 				}
 				acc |= lz | rz;
+				accr |= rz;
 				trans_octet(rs, rz, per);
 				if (h <= 8) {
 					emit_octet(rs, rz, h, 0, row, q);
@@ -1177,10 +1213,11 @@ struct Group {
 				}
 			}
 			any |= wave_any(acc);
+			anyr |= wave_any(accr);
 		}
 		wave_sync();
 		if (h > 8)
-			trans_emit(ts, tz, h, 0, row);
+			trans_emit(ts, tz, h, 0, row, anyr != 0);
 		return any;
 	}
 	PDEV void rate1_comb_any(int lvl, u32 hrd, u32 row)
