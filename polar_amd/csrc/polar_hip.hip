@@ -59,8 +59,9 @@ struct DecodeArgs {
 // Persistent wavefronts: block b walks the groups b, b + gridDim, ... Blocks are dealt to
 // the 8 XCDs round-robin, so within one sweep the blocks that share an XCD (equal b % 8) take
 // neighbouring groups: those groups share the 128-byte lines of every input row.
-// 128 VGPRs for every variant: with more (tried: 180 for the 8-per-CU variants) the wavefronts of a
-// CU no longer fit unless they spread evenly over the SIMDs, and the kernel ran 15 % slower.
+// The occupancy hint stays at 4 waves per SIMD for every variant. The 20 KiB-of-LDS variants
+// cannot reach it (8 workgroups per CU) and the compiler then uses ~200 VGPRs anyway, but asking
+// for 2 instead made it schedule the chain loops worse: 15 % slower, measured A/B on one box.
 template <int Q, int RL>
 __global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
 {
@@ -106,9 +107,10 @@ struct KernelVariant {
 	int q, rl;
 	decode_kernel_t fn;
 	size_t lds_bytes;
+	int chain_depth;
 };
 
-#define VARIANT(q, rl) {q, rl, sc_decode_kernel<q, rl>, sizeof(u32) * (size_t)Group<q, rl>::LDS_DWORDS}
+#define VARIANT(q, rl) {q, rl, sc_decode_kernel<q, rl>, sizeof(u32) * (size_t)Group<q, rl>::LDS_DWORDS, Group<q, rl>::CHAIN_DEPTH}
 static const KernelVariant g_variants[] = {
 	// 256 frames per wavefront: every node keeps all 64 lanes busy
 	VARIANT(64, 4), VARIANT(64, 5), VARIANT(64, 6), VARIANT(32, 5), VARIANT(32, 6), VARIANT(32, 7),
@@ -535,15 +537,16 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	const KernelVariant *v = pick_variant(h, lp.host.top, frames, budget);
 	if (!v)
 		return fail(POLAR_E_ARG, "no kernel variant for the configured (frames_per_wave, lds_level)");
-	if (!lp.dev.count(v->q)) { // first use with this wavefront shape: fuse and upload
+	const int shape = v->q * 8 + v->chain_depth;
+	if (!lp.dev.count(shape)) { // first use with this wavefront shape: fuse and upload
 		HostProgram hp;
-		if (translate_program(lp.bytes.data(), (int)lp.bytes.size(), hp, v->q))
+		if (translate_program(lp.bytes.data(), (int)lp.bytes.size(), hp, v->q, v->chain_depth))
 			return fail(POLAR_E_PROGRAM, "program translation failed");
 		DevOp *d = nullptr;
 		size_t bytes = hp.ops.size() * sizeof(DevOp);
 		HIP_TRY(hipMalloc((void **)&d, bytes));
 		HIP_TRY(hipMemcpy(d, hp.ops.data(), bytes, hipMemcpyHostToDevice));
-		lp.dev[v->q] = d;
+		lp.dev[shape] = d;
 	}
 	const size_t fpw = 4 * (size_t)v->q, n = (size_t)1 << lp.host.top, rows = lp.host.rows;
 	size_t groups = (frames + fpw - 1) / fpw;
@@ -592,7 +595,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	if (getenv("POLAR_HIP_DEBUG"))
 		fprintf(stderr, "polar_hip: decode Q=%d RL=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d\n", v->q, v->rl, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct);
 	DecodeArgs a;
-	a.prog = lp.dev[v->q];
+	a.prog = lp.dev[shape];
 	a.cw = cw;
 	a.msg = msg;
 	a.stride = padded;
@@ -626,7 +629,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 		static unsigned long long host[16 * 32 * 2];
 		HIP_TRY(hipMemcpyAsync(host, prof_dev, sizeof(host), hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
-		static const char *names[16] = {"left", "right", "comb", "rate0", "rate1", "rep", "spc", "r0right", "r0comb", "r1comb", "?", "chain1", "chain2", "chain3", "?", "?"};
+		static const char *names[16] = {"left", "right", "comb", "rate0", "rate1", "rep", "spc", "r0right", "r0comb", "r1comb", "?", "chain1", "chain2", "chain3", "chain4", "?"};
 		unsigned long long total = 0;
 		for (int i = 0; i < 16 * 32; ++i)
 			total += host[2 * i];

@@ -27,9 +27,9 @@ enum { MAX_LEVEL = 24 };
 // one of its asserts (polar_decoder.hh:135, :170, :202, :463 ...) or run outside its arrays.
 // Fuse runs "left|right|rate0_right at level l, then left|rate0_right at l-1, l-2, ..." (the
 // descent into a child always starts with one of these, polar_compiler.hh:34-47) into OP_CHAIN
-// words of depth <= CHAIN_MAX. A stage whose output only feeds a rate0_right stage of the same
+// words of depth <= max_depth (Group::CHAIN_DEPTH of the kernel variant). A stage whose output only feeds a rate0_right stage of the same
 // chain is not stored: no later `right` reads that level (rate0_right replaces left + right).
-inline void fuse_chains(std::vector<DevOp> &ops, int q)
+inline void fuse_chains(std::vector<DevOp> &ops, int q, int max_depth)
 {
 	std::vector<DevOp> out;
 	auto soft = [](const DevOp &d) { uint32_t o = d.op_level & 255; return o == OP_LEFT || o == OP_RIGHT || o == OP_RATE0_RIGHT; };
@@ -40,17 +40,17 @@ inline void fuse_chains(std::vector<DevOp> &ops, int q)
 		}
 		int lvl = (int)(ops[i].op_level >> 8), depth = 1;
 		uint32_t first = ops[i].op_level & 255;
-		uint32_t pad = (first == OP_LEFT ? 0u : first == OP_RIGHT ? 1u : 2u) << 2;
+		uint32_t pad = (first == OP_LEFT ? 0u : first == OP_RIGHT ? 1u : 2u) << 3;
 		// deeper only while every lane of the wave still owns a word of the last level: below
 		// that, fusing trades parallel lanes for serial work in one lane
-		while (depth < CHAIN_MAX && i + depth < ops.size() && ((size_t)q << (lvl - depth - 1)) >= 64) {
+		while (depth < max_depth && i + depth < ops.size() && ((size_t)q << (lvl - depth - 1)) >= 64) {
 			const DevOp &n = ops[i + depth];
 			uint32_t o = n.op_level & 255;
 			if ((o != OP_LEFT && o != OP_RATE0_RIGHT) || (int)(n.op_level >> 8) != lvl - depth)
 				break;
 			++depth;
 			if (o == OP_RATE0_RIGHT)
-				pad |= 1u << (3 + depth) | 1u << (8 + depth - 1);
+				pad |= 1u << (4 + depth) | 1u << (12 + depth - 1);
 		}
 		DevOp c = {OP_CHAIN | (uint32_t)lvl << 8, ops[i].hrd, 0, pad | (uint32_t)depth};
 		out.push_back(c);
@@ -60,7 +60,7 @@ inline void fuse_chains(std::vector<DevOp> &ops, int q)
 }
 
 // fuse_q: frame quads per wavefront of the kernel that will run the program (0 = no fusion)
-inline int translate_program(const uint8_t *prog, int length, HostProgram &out, int fuse_q = 0)
+inline int translate_program(const uint8_t *prog, int length, HostProgram &out, int fuse_q = 0, int max_depth = CHAIN_MAX)
 {
 	if (length < 2)
 		return 1;
@@ -136,7 +136,7 @@ inline int translate_program(const uint8_t *prog, int length, HostProgram &out, 
 	if (lvl != top)
 		return 10;
 	if (fuse_q)
-		fuse_chains(out.ops, fuse_q);
+		fuse_chains(out.ops, fuse_q, max_depth < CHAIN_MAX ? max_depth : (int)CHAIN_MAX);
 	DevOp e = {OP_END, 0, 0, 0};
 	out.ops.push_back(e);
 	out.ops.push_back(e); // the interpreter fetches one word ahead

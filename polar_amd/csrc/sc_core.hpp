@@ -48,9 +48,9 @@ enum : u32 {
 	OP_CHAIN = 16,
 	OP_END = 255
 };
-enum { CHAIN_MAX = 3 };
-// DevOp.pad of OP_CHAIN: bits 0-1 depth D, bits 2-3 kind of stage 1 (0 = f, 1 = g, 2 = qadd),
-// bit 3+k kind of stage k >= 2 (0 = f, 1 = qadd), bit 8+k: output of stage k is not stored (it
+enum { CHAIN_MAX = 4 }; // per kernel variant: Group::CHAIN_DEPTH
+// DevOp.pad of OP_CHAIN: bits 0-2 depth D, bits 3-4 kind of stage 1 (0 = f, 1 = g, 2 = qadd),
+// bit 4+k kind of stage k >= 2 (0 = f, 1 = qadd), bit 12+k: output of stage k is not stored (it
 // only feeds a rate0_right stage of the same chain)
 
 
@@ -93,9 +93,9 @@ PDEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
 PDEV u32 wave_any(u32 v) { return __builtin_amdgcn_ballot_w64(v != 0) != 0; }
 #endif
 
-PDEV int chain_depth(u32 pad) { return (int)(pad & 3); }
-PDEV int chain_kind(u32 pad, int k) { return k == 1 ? (int)((pad >> 2) & 3) : ((pad >> (3 + k)) & 1 ? 2 : 0); }
-PDEV bool chain_skip(u32 pad, int k) { return (pad >> (8 + k)) & 1; }
+PDEV int chain_depth(u32 pad) { return (int)(pad & 7); }
+PDEV int chain_kind(u32 pad, int k) { return k == 1 ? (int)((pad >> 3) & 3) : ((pad >> (4 + k)) & 1 ? 2 : 0); }
+PDEV bool chain_skip(u32 pad, int k) { return (pad >> (12 + k)) & 1; }
 
 PDEV u32 bfi(u32 mask, u32 a, u32 b) { return ((a ^ b) & mask) ^ b; } // mask ? a : b (v_bfi_b32)
 
@@ -327,6 +327,9 @@ struct Group {
 	static const int W = 1 << (RL + 1); // elements of the LDS partial-sum window
 	static const int LDS_SOFT = Q << (RL + 1), LDS_PLANE = (W / 8) * Q;
 	static const int LDS_DWORDS = LDS_SOFT + 2 * LDS_PLANE; // (128, 6): exactly 20 KiB, 8 wavefronts per CU
+	// deepest fused descent: 16 x 16-byte loads per lane need more than the 128 VGPRs that the
+	// variants with 16 wavefronts per CU have (99 spilled registers, 12 % slower when tried)
+	static const int CHAIN_DEPTH = LDS_DWORDS * 4 > 10240 ? 4 : 3;
 	lds_u32 *sl;        // LDS soft arena, LDS_SOFT dwords (level l at Q << l)
 	lds_u32 *hls, *hlz; // LDS partial-sum planes (sign, zero), LDS_PLANE dwords each, index by position mod W
 	u32 *sg;            // scratch soft arena, Q << top dwords
@@ -560,7 +563,8 @@ struct Group {
 		switch (depth) {
 		case 1: chain_at<1>(lvl, hrd, pad); break;
 		case 2: chain_at<2>(lvl, hrd, pad); break;
-		default: chain_at<3>(lvl, hrd, pad); break;
+		case 3: chain_at<3>(lvl, hrd, pad); break;
+		default: chain_at<(CHAIN_DEPTH >= 4 ? 4 : 3)>(lvl, hrd, pad); break;
 		}
 	}
 

@@ -102,11 +102,14 @@ static int run(int8_t *msg, const int8_t *cw, const HostProgram &hp, size_t fram
 extern "C" int emu_decode(int8_t *msg, const int8_t *cw, const uint8_t *prog, int len, size_t frames, int Q, int RL)
 {
 	HostProgram hp;
-	int err = translate_program(prog, len, hp, Q);
-	if (err)
-		return -err;
-#define CASE(q, r) if (Q == q && RL == r) return run<q, r>(msg, cw, hp, frames) ? -100 : (int)hp.rows;
-	CASE(1, 4) CASE(1, 6) CASE(2, 5) CASE(4, 4) CASE(4, 7) CASE(4, 9) CASE(8, 6) CASE(16, 7) CASE(16, 5) CASE(32, 5)
+	int err;
+#define CASE(q, r) \
+	if (Q == q && RL == r) { \
+		if ((err = translate_program(prog, len, hp, q, Group<q, r>::CHAIN_DEPTH))) \
+			return -err; \
+		return run<q, r>(msg, cw, hp, frames) ? -100 : (int)hp.rows; \
+	}
+	CASE(1, 4) CASE(1, 6) CASE(2, 5) CASE(4, 4) CASE(4, 7) CASE(4, 9) CASE(8, 6) CASE(16, 7) CASE(16, 5) CASE(32, 5) CASE(32, 6)
 #undef CASE
 	return -101;
 }

@@ -157,7 +157,7 @@ def test_emulated_core_every_opcode(emu, oracle):
     assert seen == set(range(10))
 
 
-@pytest.mark.parametrize("Q,RL", [(16, 5), (4, 9), (16, 7), (32, 5)])
+@pytest.mark.parametrize("Q,RL", [(16, 5), (4, 9), (16, 7), (32, 5), (32, 6)])
 def test_emulated_core_big_leaves(emu, oracle, Q, RL):
     """Leaf nodes of 128..1024 elements as the whole code, as a right child and as a left child:
     the wide (16-byte) spc / plane paths with the node in LDS, at the LDS boundary and in scratch."""
@@ -191,6 +191,7 @@ def test_emulated_core_golden_digest(emu, oracle, golden):
         llr = family_llr(k["family"], k["llr_seed"], cw)
         assert "%016x" % fnv1a64(_emu_decode(emu, llr, prog, 4, 9)) == k["out_fnv"]
         assert "%016x" % fnv1a64(_emu_decode(emu, llr, prog, 16, 7)) == k["out_fnv"]
+        assert "%016x" % fnv1a64(_emu_decode(emu, llr, prog, 32, 6)) == k["out_fnv"]  # the default shape, depth-4 chains
 
 
 def test_cpp_dropin_header_compiles():
