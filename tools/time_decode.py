@@ -47,8 +47,12 @@ out = torch.empty((N // 2, a.frames), dtype=torch.int8, device="cuda")
 dec = polar_amd.PolarDecoder(sess)
 ms = []
 for _ in range(a.reps):
+    import time
+    t0 = time.perf_counter()
     dec(out, llr, prog)
+    wall = (time.perf_counter() - t0) * 1e3
     ms.append(sess.last_decode_ms())
+    print("  call wall %.2f ms, kernel %.2f ms" % (wall, ms[-1]), flush=True)
 best = min(ms)
 bad = 0
 for r in range(0, N // 2, 1024):
