@@ -52,7 +52,6 @@ struct DecodeArgs {
 	size_t stride;         // bytes per row of cw and msg: a multiple of 4, groups * 4Q <= stride
 	u32 groups;
 	int top;
-	u32 stagger_ticks;     // start of block b is delayed by frac(b * phi) * stagger_ticks (100 MHz ticks)
 	unsigned long long *prof; // diagnostic build (POLAR_PROFILE) only
 };
 
@@ -82,14 +81,6 @@ __global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
 #ifdef POLAR_PROFILE
 	g.prof = a.prof;
 #endif
-	if (a.stagger_ticks) {
-		// Wavefronts that start together stay in step through the whole program and hit its
-		// HBM-heavy upper levels all at once; spreading the starts over one pass evens that out.
-		unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-		unsigned long long wait = ((unsigned long long)((b * 2654435769u) >> 8) * a.stagger_ticks) >> 24;
-		while (__builtin_amdgcn_s_memrealtime() - t0 < wait)
-			__builtin_amdgcn_s_sleep(64);
-	}
 	for (u32 base = 0; base < a.groups; base += nb) {
 		u32 grp = base + slot;
 		if (grp >= a.groups)
@@ -603,9 +594,6 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	a.top = lp.host.top;
 	a.scratch = nullptr;
 	a.block_dwords = 0;
-	a.stagger_ticks = 0;
-	if (const char *e = getenv("POLAR_HIP_STAGGER_US"))
-		a.stagger_ticks = (u32)(atof(e) * 100.0);
 	if (block_dwords) {
 		a.block_dwords = block_dwords;
 		if ((rc = h->scratch.reserve(blocks * block_dwords * sizeof(u32))))

@@ -1178,6 +1178,60 @@ struct Group {
 		int j0 = (int)(o.eb & 7); // nonzero only when the whole node fits one octet
 		int il0 = pidx(c.eb, 0), ol0 = pidx(o.eb, 0), or0 = pidx(o.eb + h, 0);
 		u32 anyr = 0;
+		if (Q % 4 == 0 && n >= 256) { // h >= 8: four frame quads per lane, sixteen 16-byte loads in flight
+			PFOR_LANES(lane) {
+				u32 acc = 0, accr = 0;
+				for (int t = lane * 4; t < n; t += 256) {
+					int oc = t / Q, q = t % Q;
+					u32x4 x[8], y[8];
+#pragma unroll
+					for (int j = 0; j < 8; ++j) {
+						x[j] = ldE(src, (8 * oc + j) * Q + q, u32x4());
+						y[j] = ldE(src, (8 * oc + j + h) * Q + q, u32x4());
+					}
+					u32x4 lsv = ldp4(c.s + il0 + t), lzv;
+					if (fl)
+						lzv = ldp4(c.z + il0 + t);
+					else
+						lzv.x = lzv.y = lzv.z = lzv.w = 0;
+					u32 ls[4] = {lsv.x, lsv.y, lsv.z, lsv.w}, lz[4] = {lzv.x, lzv.y, lzv.z, lzv.w};
+					u32 rs[4] = {0, 0, 0, 0}, rz[4] = {0, 0, 0, 0};
+#pragma unroll
+					for (int j = 0; j < 8; ++j) {
+						u32 xc[4] = {x[j].x, x[j].y, x[j].z, x[j].w}, yc[4] = {y[j].x, y[j].y, y[j].z, y[j].w};
+#pragma unroll
+						for (int k = 0; k < 4; ++k) {
+							u32 r = madd4(ls[k] << j, lz[k] << j, xc[k], yc[k]);
+							rs[k] |= (r & SIGN_BITS) >> j;
+							rz[k] |= zero_bytes(r) >> j;
+						}
+					}
+					u32x4 v;
+					v.x = ls[0] ^ rs[0]; v.y = ls[1] ^ rs[1]; v.z = ls[2] ^ rs[2]; v.w = ls[3] ^ rs[3];
+					stp4(o.s + ol0 + t, v);
+					v.x = lz[0] | rz[0]; v.y = lz[1] | rz[1]; v.z = lz[2] | rz[2]; v.w = lz[3] | rz[3];
+					stp4(o.z + ol0 + t, v);
+					acc |= v.x | v.y | v.z | v.w;
+					v.x = rs[0]; v.y = rs[1]; v.z = rs[2]; v.w = rs[3];
+					stp4(o.s + or0 + t, v);
+					v.x = rz[0]; v.y = rz[1]; v.z = rz[2]; v.w = rz[3];
+					stp4(o.z + or0 + t, v);
+					accr |= v.x | v.y | v.z | v.w;
+#pragma unroll
+					for (int k = 0; k < 4; ++k)
+						trans_octet(rs[k], rz[k], 8);
+					v.x = rs[0]; v.y = rs[1]; v.z = rs[2]; v.w = rs[3];
+					stp4(ts + t, v);
+					v.x = rz[0]; v.y = rz[1]; v.z = rz[2]; v.w = rz[3];
+					stp4(tz + t, v);
+				}
+				any |= wave_any(acc);
+				anyr |= wave_any(accr);
+			}
+			wave_sync();
+			trans_emit(ts, tz, h, 0, row, anyr != 0);
+			return any;
+		}
 		PFOR_LANES(lane) {
 			u32 acc = 0, accr = 0;
 			for (int t = lane; t < n; t += 64) {
