@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
 	g.hls = g.sl + G::LDS_SOFT;
 	g.hlz = g.hls + G::LDS_PLANE;
 	g.sg = arena;
-	g.hgs = arena ? arena + skew((size_t)Q << a.top) : nullptr;
+	g.hgs = arena ? arena + ((size_t)Q << a.top) : nullptr;
 	g.hgz = arena ? g.hgs + plane : nullptr;
 	g.top = a.top;
 	g.keep_below = a.keep_below;
@@ -472,7 +472,7 @@ static const KernelVariant *find_variant(int q, int rl)
 static size_t scratch_bytes_per_wave(int q, int top)
 {
 	size_t soft = (size_t)q << top;
-	return (skew(soft) + 2 * (soft / 8)) * sizeof(u32);
+	return (soft + 2 * (soft / 8)) * sizeof(u32);
 }
 
 // Default shape: the 20 KiB-of-LDS family (8 wavefronts per CU), widest first. 128 frames per
@@ -571,9 +571,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	size_t block_dwords = 0, max_blocks = ~(size_t)0 >> 8;
 	if (lp.host.top > v->rl) { // LLR levels above the LDS levels and the partial-sum planes live in scratch
 		size_t soft = (size_t)v->q << lp.host.top;
-		block_dwords = skew(soft) + 2 * (soft / 8);
-		if (const char *e = getenv("POLAR_HIP_ARENA_PAD"))
-			block_dwords += (size_t)atol(e) / 4 * 4;
+		block_dwords = soft + 2 * (soft / 8);
 		if (!budget.fits(blocks * block_dwords * sizeof(u32))) { // fewer resident wavefronts, more sweeps
 			max_blocks = budget.limit() / (block_dwords * sizeof(u32));
 			if (max_blocks < 1)

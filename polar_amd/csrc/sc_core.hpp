@@ -205,49 +205,28 @@ PDEV u32x4 qadd4(u32x4 a, u32x4 b) { u32x4 r; r.x = qadd4(a.x, b.x); r.y = qadd4
 // the same wavefront, far beyond what L2 or the Infinity Cache can hold in between. Marking the
 // 16-byte accesses non-temporal keeps them from evicting lines that do get reused (+8 % at
 // N = 2^16). POLAR_NO_NT restores default-policy accesses for comparison.
-// Index -> dword offset inside a wavefront's LLR scratch: every 2^SKEW_SHIFT dwords (32 KiB) the
-// arena slips by SKEW_PAD dwords (one 128-byte line). The words one lane-iteration of a fused
-// chain touches lie powers of two apart (t + j * 2^k, and one level is 2x the next); unskewed
-// the kernel time flips between 233 and 254 ms from process to process (physical placement),
-// with this slip it stays at 240 ms. Slips that are not whole lines, or come every 4 KiB, were
-// slower (up to 270 ms): they break the 1 KiB alignment of the wave-wide accesses too often.
-#ifndef POLAR_SKEW_SHIFT
-#define POLAR_SKEW_SHIFT 13
-#endif
-#ifndef POLAR_SKEW_PAD
-#define POLAR_SKEW_PAD 32
-#endif
-#ifdef POLAR_EMU
-inline
-#else
-__host__ __device__ __forceinline__
-#endif
-size_t skew(size_t i) { return i + (i >> POLAR_SKEW_SHIFT) * POLAR_SKEW_PAD; }
-
-struct GVec { // dword array in the HBM scratch arena: element t of the vector that starts at index base
-	u32 *arena;
-	int base;
-	bool keep; // default cache policy (the level is re-read soon enough to stay cached)
-	PDEV u32 *at(int t) const { return arena + skew((size_t)(base + t)); }
-	PDEV u32 ld(int t) const { return *at(t); }
-	PDEV void st(int t, u32 v) const { *at(t) = v; }
+struct GVec { // linear dword array in the HBM scratch arena
+	u32 *p;
+	bool keep = false; // default cache policy (the level is re-read soon enough to stay cached)
+	PDEV u32 ld(int t) const { return p[t]; }
+	PDEV void st(int t, u32 v) const { p[t] = v; }
 #if !defined(POLAR_EMU) && !defined(POLAR_NO_NT)
 	PDEV u32x4 ld4(int t) const
 	{
 		if (keep)
-			return *reinterpret_cast<const u32x4 *>(at(t));
-		return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(at(t)));
+			return *reinterpret_cast<const u32x4 *>(p + t);
+		return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + t));
 	}
 	PDEV void st4(int t, u32x4 v) const
 	{
 		if (keep)
-			*reinterpret_cast<u32x4 *>(at(t)) = v;
+			*reinterpret_cast<u32x4 *>(p + t) = v;
 		else
-			__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(at(t)));
+			__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p + t));
 	}
 #else
-	PDEV u32x4 ld4(int t) const { return *reinterpret_cast<const u32x4 *>(at(t)); }
-	PDEV void st4(int t, u32x4 v) const { *reinterpret_cast<u32x4 *>(at(t)) = v; }
+	PDEV u32x4 ld4(int t) const { return *reinterpret_cast<const u32x4 *>(p + t); }
+	PDEV void st4(int t, u32x4 v) const { *reinterpret_cast<u32x4 *>(p + t) = v; }
 #endif
 };
 
@@ -377,7 +356,7 @@ struct Group {
 #endif
 
 	int keep_below; // scratch levels below this one use the default cache policy, the others stream
-	PDEV GVec gvec(int lvl) const { return GVec{sg, Q << lvl, lvl < keep_below}; }
+	PDEV GVec gvec(int lvl) const { return GVec{sg + (Q << lvl), lvl < keep_below}; }
 
 	// plane dword of element e for frame quad q
 	static PDEV int pidx(u32 e, int q) { return (int)(e >> 3) * Q + q; }
@@ -393,20 +372,19 @@ struct Group {
 	}
 	PDEV u32 *fregion(int lvl) const // flat pointer to the level-lvl LLR region (lvl < top)
 	{
-		if (lvl > RL) // linear use inside the region is fine: the skewed region is at least as long
-			return sg + skew((size_t)Q << lvl);
+		if (lvl > RL)
+			return sg + (Q << lvl);
 		return (u32 *)sl + (Q << lvl);
 	}
 
 	// LLR vector of a node above the LDS levels (or the input), runtime placement
 	struct AnySrc {
 		const Group *g;
-		GVec v;
-		bool input; // the caller's buffer
-		PDEV u32 ld(int t) const { return input ? g->in.ld(t) : v.ld(t); }
-		PDEV u32x4 ld4(int t) const { return input ? g->in.ld4(t) : v.ld4(t); }
+		const u32 *base; // null: the caller's input
+		PDEV u32 ld(int t) const { return base ? base[t] : g->in.ld(t); }
+		PDEV u32x4 ld4(int t) const { return base ? ldp4(base + t) : g->in.ld4(t); }
 	};
-	PDEV AnySrc any_src(int lvl) const { return AnySrc{this, gvec(lvl), lvl == top}; }
+	PDEV AnySrc any_src(int lvl) const { return AnySrc{this, lvl == top ? nullptr : fregion(lvl)}; }
 
 	// ---- f / g / qadd passes: polar_decoder.hh:28-51 ----
 	template <int KIND, class A, class D, class H>
@@ -439,7 +417,7 @@ struct Group {
 			else
 				pass<KIND>(LVec{sl + 2 * n}, d, n, hls, hlz, eb);
 		} else {
-			GVec d = gvec(lvl - 1);
+			GVec d{sg + n};
 			if (lvl == top)
 				pass<KIND>(in, d, n, hgs, hgz, hrd);
 			else
@@ -483,7 +461,7 @@ struct Group {
 	PDEV void stE(int level, int t, u32 v) const
 	{
 		if (level > RL)
-			gvec(level).st(t, v);
+			sg[(Q << level) + t] = v;
 		else
 			sl[(Q << level) + t] = v;
 	}

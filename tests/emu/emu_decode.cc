@@ -74,9 +74,9 @@ static int run(int8_t *msg, const int8_t *cw, const HostProgram &hp, size_t fram
 		memcpy(&pin[i * fp], cw + i * frames, frames);
 	// same arena layout as the kernel (polar_hip.hip): soft, sign plane, zero plane; 16-byte aligned
 	const size_t nsoft = (size_t)Q << hp.top, nplane = nsoft / 8 + 1;
-	std::vector<u32x4> lds_((G::LDS_DWORDS + 3) / 4), soft_((skew(nsoft) + 3) / 4 + 1), planes_((2 * nplane + 3) / 4 + 1);
+	std::vector<u32x4> lds_((G::LDS_DWORDS + 3) / 4), soft_((nsoft + 3) / 4), planes_((2 * nplane + 3) / 4 + 1);
 	struct Span { u32 *p; size_t n; u32 *data() { return p; } u32 *begin() { return p; } u32 *end() { return p + n; } size_t size() const { return n; } };
-	Span lds{(u32 *)lds_.data(), (size_t)G::LDS_DWORDS}, soft{(u32 *)soft_.data(), skew(nsoft)}, planes{(u32 *)planes_.data(), 2 * nplane};
+	Span lds{(u32 *)lds_.data(), (size_t)G::LDS_DWORDS}, soft{(u32 *)soft_.data(), nsoft}, planes{(u32 *)planes_.data(), 2 * nplane};
 	for (size_t g0 = 0; g0 < fp; g0 += FR) {
 		// poison everything a fresh wave would find uninitialised
 		for (auto &v : lds) v = 0xDEADBEEF;
