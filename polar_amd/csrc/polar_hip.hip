@@ -52,7 +52,6 @@ struct DecodeArgs {
 	size_t stride;         // bytes per row of cw and msg: a multiple of 4, groups * 4Q <= stride
 	u32 groups;
 	int top;
-	int keep_below;        // scratch levels below this keep the default cache policy
 	unsigned long long *prof; // diagnostic build (POLAR_PROFILE) only
 };
 
@@ -79,7 +78,6 @@ __global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
 	g.hgs = arena ? arena + ((size_t)Q << a.top) : nullptr;
 	g.hgz = arena ? g.hgs + plane : nullptr;
 	g.top = a.top;
-	g.keep_below = a.keep_below;
 #ifdef POLAR_PROFILE
 	g.prof = a.prof;
 #endif
@@ -594,12 +592,6 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	a.stride = padded;
 	a.groups = (u32)groups;
 	a.top = lp.host.top;
-	// the first scratch level is re-read within ~50 us and 8 wavefronts x 16 KiB of it fit the
-	// XCD's L2 beside the streams: default cache policy there, non-temporal above (measured:
-	// 235 ms vs 230-251 ms run to run at N = 2^16)
-	a.keep_below = v->rl + 2;
-	if (const char *e = getenv("POLAR_HIP_KEEP_BELOW"))
-		a.keep_below = atoi(e);
 	a.scratch = nullptr;
 	a.block_dwords = 0;
 	if (block_dwords) {

@@ -207,25 +207,16 @@ PDEV u32x4 qadd4(u32x4 a, u32x4 b) { u32x4 r; r.x = qadd4(a.x, b.x); r.y = qadd4
 // N = 2^16). POLAR_NO_NT restores default-policy accesses for comparison.
 struct GVec { // linear dword array in the HBM scratch arena
 	u32 *p;
-	bool keep = false; // default cache policy (the level is re-read soon enough to stay cached)
 	PDEV u32 ld(int t) const { return p[t]; }
 	PDEV void st(int t, u32 v) const { p[t] = v; }
 #if !defined(POLAR_EMU) && !defined(POLAR_NO_NT)
-	PDEV u32x4 ld4(int t) const
-	{
-		if (keep)
-			return *reinterpret_cast<const u32x4 *>(p + t);
-		return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + t));
-	}
-	PDEV void st4(int t, u32x4 v) const
-	{
-		if (keep)
-			*reinterpret_cast<u32x4 *>(p + t) = v;
-		else
-			__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p + t));
-	}
+	PDEV u32x4 ld4(int t) const { return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + t)); }
 #else
 	PDEV u32x4 ld4(int t) const { return *reinterpret_cast<const u32x4 *>(p + t); }
+#endif
+#if !defined(POLAR_EMU) && !defined(POLAR_NO_NT)
+	PDEV void st4(int t, u32x4 v) const { __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p + t)); }
+#else
 	PDEV void st4(int t, u32x4 v) const { *reinterpret_cast<u32x4 *>(p + t) = v; }
 #endif
 };
@@ -355,9 +346,6 @@ struct Group {
 	unsigned long long *prof; // [16 node kinds][32 levels][cycles, calls], diagnostic build only
 #endif
 
-	int keep_below; // scratch levels below this one use the default cache policy, the others stream
-	PDEV GVec gvec(int lvl) const { return GVec{sg + (Q << lvl), lvl < keep_below}; }
-
 	// plane dword of element e for frame quad q
 	static PDEV int pidx(u32 e, int q) { return (int)(e >> 3) * Q + q; }
 
@@ -413,7 +401,7 @@ struct Group {
 			if (lvl == top)
 				pass<KIND>(in, d, n, hls, hlz, eb);
 			else if (lvl > RL)
-				pass<KIND>(gvec(lvl), d, n, hls, hlz, eb);
+				pass<KIND>(GVec{sg + 2 * n}, d, n, hls, hlz, eb);
 			else
 				pass<KIND>(LVec{sl + 2 * n}, d, n, hls, hlz, eb);
 		} else {
@@ -421,7 +409,7 @@ struct Group {
 			if (lvl == top)
 				pass<KIND>(in, d, n, hgs, hgz, hrd);
 			else
-				pass<KIND>(gvec(lvl), d, n, hgs, hgz, hrd);
+				pass<KIND>(GVec{sg + 2 * n}, d, n, hgs, hgz, hrd);
 		}
 	}
 
@@ -468,7 +456,7 @@ struct Group {
 	PDEV void stE(int level, int t, u32x4 v) const
 	{
 		if (level > RL)
-			gvec(level).st4(t, v);
+			GVec{sg + (Q << level)}.st4(t, v);
 		else
 			LVec{sl + (Q << level)}.st4(t, v);
 	}
@@ -544,14 +532,14 @@ struct Group {
 			if (lvl == top)
 				chain_run<D, true>(in, lvl, pad, hls, hlz, eb);
 			else if (lvl > RL)
-				chain_run<D, true>(gvec(lvl), lvl, pad, hls, hlz, eb);
+				chain_run<D, true>(GVec{sg + (Q << lvl)}, lvl, pad, hls, hlz, eb);
 			else
 				chain_run<D, true>(LVec{sl + (Q << lvl)}, lvl, pad, hls, hlz, eb);
 		} else { // scratch planes: only reached when the child's zero plane is empty (chain())
 			if (lvl == top)
 				chain_run<D, false>(in, lvl, pad, hgs, hgz, hrd);
 			else
-				chain_run<D, false>(gvec(lvl), lvl, pad, hgs, hgz, hrd);
+				chain_run<D, false>(GVec{sg + (Q << lvl)}, lvl, pad, hgs, hgz, hrd);
 		}
 	}
 	PDEV void chain(int lvl, u32 hrd, u32 pad)

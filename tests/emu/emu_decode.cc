@@ -90,7 +90,6 @@ static int run(int8_t *msg, const int8_t *cw, const HostProgram &hp, size_t fram
 		g.hgs = planes.data();
 		g.hgz = planes.data() + nsoft / 8;
 		g.top = hp.top;
-		g.keep_below = 0;
 		g.in = InVec<Q>{(const uint8_t *)pin.data() + g0, fp};
 		g.out = OutRows<Q>{(uint8_t *)pout.data() + g0, fp};
 		g.run(hp.ops.data());
