@@ -6,8 +6,9 @@ import collections
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-from oracle_lib import Oracle  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np  # noqa: E402
+import polar_amd  # noqa: E402  (host-side construction and compiler of the library itself)
 
 
 def main():
@@ -16,11 +17,12 @@ def main():
     ap.add_argument("--rl", type=int, default=7)
     ap.add_argument("--fuse", type=int, default=3)
     a = ap.parse_args()
-    o = Oracle()
     N = 1 << a.M
-    fro = o.const0(a.M, N // 2)
-    fro = fro[0] if isinstance(fro, tuple) else fro
-    prog = [int(x) for x in o.compile(fro, a.M)]
+    fro = np.zeros(N, np.uint8)
+    polar_amd.PolarCodeConst0()(fro, a.M, N // 2, polar_amd.testbench_probability())
+    buf = np.zeros(2 * N + 2, np.uint8)
+    n = polar_amd.PolarCompiler()(buf, fro, a.M)
+    prog = [int(x) for x in buf[:n]]
     top, RL = a.M, a.rl
     rd = collections.Counter()
     wr = collections.Counter()
