@@ -65,8 +65,10 @@ int polar_program_rows(const uint8_t *program, int length);
 int polar_hip_create(polar_hip_handle **out, int device);
 void polar_hip_destroy(polar_hip_handle *h);
 
-/* Tuning: frames per wavefront (4, 8, 16, 32 or 64), highest LLR level staged in LDS, and
- * the number of resident wavefronts (0 = fill the device). Defaults are chosen per code size. */
+/* Tuning: frames per wavefront (4 ... 256) and highest LLR level staged in LDS -- one of the
+ * compiled kernel variants, e.g. (128, 6), (64, 7), (256, 5), (16, 9); POLAR_E_ARG otherwise --
+ * and the number of resident wavefronts (0 = fill the device). frames_per_wave = 0 restores the
+ * default: chosen per call from the batch size, the code size and the free device memory. */
 int polar_hip_configure(polar_hip_handle *h, int frames_per_wave, int lds_level, int max_waves);
 
 /* Uploads a PolarCompiler program as the constant-memory instruction stream; returns a
@@ -77,7 +79,8 @@ int polar_hip_load_program(polar_hip_handle *h, const uint8_t *program, int leng
  * for `frames` frames at once. codeword: N x frames int8 LLRs (not modified);
  * message: K x frames int8 decisions. `where` says whether both pointers are host or device. */
 int polar_hip_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, int where);
-/* Same, enqueued on `stream` (a hipStream_t) without synchronising; device pointers only. */
+/* Same, enqueued on `stream` (a hipStream_t) without synchronising; device pointers only. A
+ * handle owns one scratch arena: keep its launches on one stream (any mix of programs). */
 int polar_hip_decode_async(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, void *stream);
 
 /* PolarEncoder<TYPE,M>::operator() polar_encoder.hh:15-27 (systematic = 0) and
