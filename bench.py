@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: batched int8 SC decoding of the rate-1/2 N=2^16 polar code.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames F] [--config A|B|D]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no RANK in the environment starts the N ranks itself (one child
+process per GPU, spawned before this process touches HIP; RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* are set for them exactly as torch.distributed.run would). Under torchrun the ranks
+already exist and `--gpus` must equal WORLD_SIZE.
 
 One "step" = one pass of the hot path over one resident batch: the SC decode kernel over F
 frames per GPU (BASELINE.json configs[1]: N=2^16, K=32768, systematic, 2^20 frames) -- the
@@ -10,7 +15,8 @@ region the reference itself times (testbench.cc:170-174). The timed region of th
 ends with the bench's error counters (testbench.cc:189-192) over the decoded batch on the
 device and, with more than one rank, the RCCL all-reduce of those counters (configs[2],
 SURVEY 8d/8e). Frames are independent, so ranks shard them with no other exchange (weak
-scaling: F frames per GPU).
+scaling: F frames per GPU). `--include-extract` adds the systematic post-processing of
+testbench.cc:177-183 (re-encode + gather, fused on the device) to every step.
 
 Inputs are synthetic and resident in HBM before the timed region: random +-1 messages,
 systematic encoding (PolarSysEnc, on device), BPSK/AWGN at Es/N0 = -1 dB, LLR = 2y/sigma^2
@@ -23,10 +29,16 @@ steps (max over ranks). `roofline` prices the decode kernel alone (HIP events on
 stream) against 8 TB/s with the algorithmic 1.5*N bytes per frame; `cpu_baseline`
 times the reference's own AVX2 decoder (oracle/_ref, built from the reference headers) on the
 host cores for a bounded sample of the same LLRs.
+
+Other configs of BASELINE.json (`--config`): A = N=2^10 non-systematic (configs[0]), D = N=2^20
+systematic (configs[3]); B (default) is the headline. They change the workload named in
+`config.workload`, nothing else.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -36,42 +48,98 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-M = 16
-N = 1 << M
-K = N // 2
 SNR_DB = -1.0
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CONFIGS = {
+    # name: (M, systematic, default frames per GPU)
+    "A": (10, 0, 1 << 22),
+    "B": (16, 1, 1 << 20),
+    "D": (20, 1, 1 << 15),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=1 << 20, help="frames per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="B")
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU (0 = the config's default)")
     ap.add_argument("--fpw", type=int, default=0, help="frames per wavefront (0 = library default)")
     ap.add_argument("--lds-level", type=int, default=0)
+    ap.add_argument("--include-extract", action="store_true", help="time re-encode + gather (testbench.cc:177-183) with every decode")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per thread (0 = skip)")
-    return ap.parse_args()
+    ap.add_argument("--plumbing-only", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo test of the rank plumbing
+    return ap.parse_args(argv)
 
 
-def make_code(polar_amd):
+# ---------------------------------------------------------------------------------------
+# rank launcher: `bench.py --gpus N` outside torchrun
+# ---------------------------------------------------------------------------------------
+
+def visible_gpus():
+    """Number of HIP devices, without initialising the runtime in this process."""
+    import torch
+
+    return torch.cuda.device_count()
+
+
+def launch_ranks(args, argv):
+    """Start one child per GPU and relay rank 0's line. The parent never initialises HIP and
+    never replaces itself: children are ordinary subprocesses."""
+    n = args.gpus
+    if not args.plumbing_only:
+        have = visible_gpus()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d asked for but only %d GPU(s) are visible on this node\n" % (n, have))
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+    line, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------
+# workload
+# ---------------------------------------------------------------------------------------
+
+def make_code(polar_amd, M):
+    N = 1 << M
     fro = np.zeros(N, np.uint8)
-    polar_amd.PolarCodeConst0()(fro, M, K, polar_amd.testbench_probability())
+    polar_amd.PolarCodeConst0()(fro, M, N // 2, polar_amd.testbench_probability())
     prog = np.zeros(2 * N + 1, np.uint8)
     n = polar_amd.PolarCompiler()(prog, fro, M)
     return fro, prog[:n].copy()
 
 
-def generate(torch, polar_amd, sess, fro, prog, frames, seed, first_frame, dev):
-    """Resident batch: llr [N][frames] int8 and the transmitted u-domain message [K][frames].
+def generate(torch, polar_amd, sess, fro, M, systematic, frames, seed, first_frame, dev):
+    """Resident batch: llr [N][frames] int8 and the decoder-domain (u) truth [K][frames].
     Message bits and noise come from the library's counter-based source (polar_hip_random_message,
     polar_hip_channel): global frame g is the same whatever rank or chunk produces it."""
+    N = 1 << M
+    K = N // 2
     llr = torch.empty((N, frames), dtype=torch.int8, device=dev)
     u_true = torch.empty((K, frames), dtype=torch.int8, device=dev)
-    enc = polar_amd.PolarSysEnc(M, sess)
-    dec = polar_amd.PolarDecoder(sess)
-    chunk = min(frames, 8192)
+    enc = (polar_amd.PolarSysEnc if systematic else polar_amd.PolarEncoder)(M, sess)
+    plain = polar_amd.PolarEncoder(M, sess)
+    chunk = max(1, min(frames, (1 << 32) // N))
     stats = torch.zeros(4, dtype=torch.int64, device=dev)
     for a in range(0, frames, chunk):
         c = min(chunk, frames - a)
@@ -83,22 +151,54 @@ def generate(torch, polar_amd, sess, fro, prog, frames, seed, first_frame, dev):
         sess.channel(q, cw, SNR_DB, seed, first_frame + a)
         sess.count(stats, q, cw, None, None)  # awgn_errors / quantization_erasures of the batch
         llr[:, a:a + c] = q
-        # u-domain truth: decoding the noise-free codeword returns the encoder's input
-        clean = (cw * 64).contiguous()
-        u = torch.empty((K, c), dtype=torch.int8, device=dev)
-        dec(u, clean, prog)
-        u_true[:, a:a + c] = u
-        del cw, q, clean, u, msg
+        if systematic:
+            # the u the decoder must return = info rows of the first encoding pass
+            # (polar_encoder.hh:40-52) = re-encode + gather of the message itself
+            plain.extract_systematic(msg, fro)
+        u_true[:, a:a + c] = msg
+        del cw, q, msg
     torch.cuda.synchronize(dev)
     return llr, u_true, stats
 
 
-def cpu_baseline(llr_sample, prog, seconds):
-    """The genuine reference decoder (PolarDecoder<SIMD<int8_t,32>>) on the host cores."""
+def systematic_errors(torch, polar_amd, sess, fro, M, out, frames, seed, first_frame, dev):
+    """testbench.cc:177-192 after the timed region: re-encode + gather the decoded u, compare with
+    the transmitted message (regenerated from the counter-based source), chunk by chunk."""
+    N = 1 << M
+    K = N // 2
+    plain = polar_amd.PolarEncoder(M, sess)
+    c4 = torch.zeros(4, dtype=torch.int64, device=dev)
+    chunk = max(1, min(frames, (1 << 31) // N))
+    for a in range(0, frames, chunk):
+        c = min(chunk, frames - a)
+        dec = out[:, a:a + c].contiguous()
+        plain.extract_systematic(dec, fro)
+        msg = torch.empty((K, c), dtype=torch.int8, device=dev)
+        sess.random_message(msg, seed, first_frame + a)
+        sess.count(c4, None, None, dec, msg)
+        del dec, msg
+    return c4
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(llr_sample, prog, K, seconds):
+    """The genuine reference decoder (PolarDecoder<SIMD<int8_t,32>>) on the host cores. The GPU
+    box gives a 1-GPU job a share of 16 CPUs (OMP_NUM_THREADS there), so 16 threads are used
+    even though os.cpu_count() reports the whole machine."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
-    threads = max(1, min(16, os.cpu_count() or 1))
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or 16
+    threads = max(1, min(share, os.cpu_count() or 1))
     if os.path.exists(oracle_lib.REF_SO):
         ref = oracle_lib.Ref()
         W = ref.width
@@ -113,8 +213,9 @@ def cpu_baseline(llr_sample, prog, seconds):
 
         def timed(bundle, reps):
             return orc.decode_time(bundle, prog, reps)
-    bundles = [np.ascontiguousarray(llr_sample[:, t * W:(t + 1) * W]) for t in range(threads)]
-    per_call = timed(bundles[0], 20) / 20
+    have = llr_sample.shape[1] // W
+    bundles = [np.ascontiguousarray(llr_sample[:, (t % have) * W:(t % have + 1) * W]) for t in range(threads)]
+    per_call = timed(bundles[0], 3) / 3
     reps = max(1, int(seconds / per_call))
     out = [0.0] * threads
 
@@ -131,48 +232,78 @@ def cpu_baseline(llr_sample, prog, seconds):
     bits = threads * reps * W * K
     return {
         "value": bits / max(out) / 1e9, "unit": "Gbit/s", "cores": threads, "kind": kind,
-        "sample": "%d threads x %d calls x %d frames of the same N=2^16 LLR batch, decode only (wall %.1f s, %.1f us per call)" % (threads, reps, W, wall, 1e6 * max(out) / reps),
+        "host_cpus_visible": os.cpu_count(), "cpu_model": cpu_model(),
+        "sample": "%d threads x %d calls x %d frames of the same LLR batch, decode only (wall %.1f s, %.1f us per call); threads = the job's CPU share, not the machine's %s CPUs" % (
+            threads, reps, W, wall, 1e6 * max(out) / reps, os.cpu_count()),
     }
 
 
-def main():
-    args = parse()
-    import torch
+def load_profile_counters(frames, args):
+    """HBM bytes and VALU / LDS utilisation of the decode kernel from the committed rocprofv3
+    PMC passes of this same command (tools/prof_bench.sh -> profiles/hbm_traffic.json)."""
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    t = json.load(open(tpath))
+    if t.get("frames") == frames and t.get("fpw") == args.fpw and t.get("lds_level") == args.lds_level and t.get("config", "B") == args.config:
+        return t
+    return None
 
+
+def main():
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch
+
+    if args.plumbing_only:
+        return plumbing_only(torch, args, rank, world)
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d are visible" % (rank, local, torch.cuda.device_count()))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
     import polar_amd
 
+    M, systematic, default_frames = CONFIGS[args.config]
+    N = 1 << M
+    K = N // 2
+    frames = args.frames or default_frames
     sess = polar_amd.Session(local)
     if args.fpw:
         sess.configure(args.fpw, args.lds_level, 0)
-    fro, prog = make_code(polar_amd)
-    frames = args.frames
-    llr, u_true, chan = generate(torch, polar_amd, sess, fro, prog, frames, 42, rank * frames, dev)
+    fro, prog = make_code(polar_amd, M)
+    seed, first = 42, rank * frames
+    llr, u_true, chan = generate(torch, polar_amd, sess, fro, M, systematic, frames, seed, first, dev)
     out = torch.empty((K, frames), dtype=torch.int8, device=dev)
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
     dec = polar_amd.PolarDecoder(sess)
+    plain = polar_amd.PolarEncoder(M, sess)
     kernel_ms = []
 
     def step():
         dec(out, llr, prog)
         kernel_ms.append(sess.last_decode_ms())
+        if args.include_extract:
+            plain.extract_systematic(out, fro)
 
     def tally():
         # testbench.cc:189-192 once per batch, then the one collective of the job (SURVEY 8e)
         counters.zero_()
-        sess.count(counters, None, None, out, u_true)
+        sess.count(counters, None, None, out, msg_true if args.include_extract else u_true)
         if dist is not None:
             dist.all_reduce(counters)
 
@@ -182,6 +313,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    msg_true = None
+    if args.include_extract:
+        msg_true = torch.empty((K, frames), dtype=torch.int8, device=dev)
+        sess.random_message(msg_true, seed, first)
     for _ in range(args.warmup):
         step()
     tally()
@@ -193,45 +328,93 @@ def main():
     tally()
     fence()
     elapsed = time.perf_counter() - t0
+    if systematic and not args.include_extract:
+        sysc = systematic_errors(torch, polar_amd, sess, fro, M, out, frames, seed, first, dev)
+    else:
+        sysc = counters.clone()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.all_reduce(chan)
+        if systematic and not args.include_extract:
+            dist.all_reduce(sysc)
     c = counters.cpu().tolist()
+    sc = sysc.cpu().tolist()
     ch = chan.cpu().tolist()
     total_frames = frames * world
     value = total_frames * K * args.steps / elapsed / 1e9
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
-        achieved = frames * 1.5 * N / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            t = json.load(open(tpath))
-            if t.get("frames") == frames and t.get("fpw") == args.fpw and t.get("lds_level") == args.lds_level:
-                traffic = t.get("bytes_per_launch")
+        alg = frames * 1.5 * N
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        prof = load_profile_counters(frames, args)
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": prof.get("bytes_per_launch") if prof else None, "kernel": "sc_decode_kernel", "kernel_ms": k_ms,
+                "algorithmic_bytes_per_launch": alg}
+        if prof:
+            # counters of the same command under rocprofv3 (profiles/): real HBM bytes per launch
+            # over the live kernel time, and the VALU / LDS figures north_star asks for
+            roof["traffic_frac"] = prof["bytes_per_launch"] / (k_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
+            for key in ("valu_util", "lds_bw_util", "lds_bank_conflict_frac"):
+                if key in prof:
+                    roof[key] = prof[key]
+        what = "SC decode of the batch (what testbench.cc:170-174 times)"
+        if args.include_extract:
+            what += " + fused re-encode/gather (testbench.cc:177-183)"
         line = {
-            "metric": "decoded info Gbit/s (node) at N=2^16 R=1/2 int8 SC", "value": value, "unit": "Gbit/s",
+            "metric": "decoded info Gbit/s (node) at N=2^%d R=1/2 int8 SC" % M, "value": value, "unit": "Gbit/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {
-                "workload": "N=2^16 K=32768 systematic Const0 code, %d frames per GPU resident in HBM, BPSK/AWGN Es/N0=%.1f dB, int8 LLRs; step = SC decode of the batch (what testbench.cc:170-174 times); the timed region ends with one error count%s" % (frames, SNR_DB, " + RCCL all-reduce of the counters" if world > 1 else ""),
+                "workload": "config %s: N=2^%d K=%d %s Const0 code, %d frames per GPU resident in HBM, BPSK/AWGN Es/N0=%.1f dB, int8 LLRs; step = %s; the timed region ends with one error count%s" % (
+                    args.config, M, K, "systematic" if systematic else "non-systematic", frames, SNR_DB, what, " + RCCL all-reduce of the counters" if world > 1 else ""),
                 "frames_per_gpu": frames, "parallelism": "frames sharded over %d GPU(s)" % world,
                 "frames_per_wave": args.fpw or "default", "lds_level": args.lds_level or "default",
             },
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "sc_decode_kernel", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": frames * 1.5 * N},
+            "roofline": roof,
             "frac_of_hbm_roofline_whole_job": value * 1e9 * 3 / (HBM_PEAK_GBS * 1e9 * world),
-            "ber": c[2] / float(total_frames * K), "uncorrected_errors": c[2], "ambiguity_erasures": c[3],
+            # ber: the reference's figure (systematic: after re-encode + gather, testbench.cc:177-197);
+            # ber_u_domain: decoder output against the encoder's u, what the timed tally counts
+            "ber": sc[2] / float(total_frames * K), "uncorrected_errors": sc[2], "ambiguity_erasures": sc[3],
+            "ber_u_domain": c[2] / float(total_frames * K),
             "awgn_errors": ch[0], "quantization_erasures": ch[1],
         }
         if world == 1 and args.cpu_seconds > 0:
-            sample = llr[:, :16 * 32].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(sample, prog, args.cpu_seconds)
+            sample = llr[:, :16 * 32].cpu().numpy() if M <= 16 else llr[:, :32].cpu().numpy()
+            line["cpu_baseline"] = cpu_baseline(sample, prog, K, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if dist is not None:
+        dist.destroy_process_group()
+
+
+def plumbing_only(torch, args, rank, world):
+    """The rank plumbing of main() with CPU tensors over gloo (tests/test_multi_rank.py): process
+    group from the environment, barrier-bracketed timed region, counter all-reduce, max-over-ranks
+    time, one line from rank 0. No decode happens and `value` is 0."""
+    import torch.distributed as dist
+
+    from polar_amd.shard import shard_range
+
+    if world > 1:
+        dist.init_process_group("gloo")
+    frames = args.frames or 1000
+    a, b = shard_range(frames * world, rank, world)
+    counters = torch.tensor([rank + 1, b - a, 0, 0], dtype=torch.int64)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.all_reduce(counters)
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing only", "value": 0.0, "n_gpus": world, "counters": counters.tolist(),
+                          "ms_per_step": 1e3 * float(t.item()), "plumbing_only": True}), flush=True)
+    if world > 1:
         dist.destroy_process_group()
 
 

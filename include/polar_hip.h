@@ -17,6 +17,15 @@
  *
  * Threading: a handle owns device scratch, like the reference functor objects own theirs
  * (polar_decoder.hh:128-129); one call at a time per handle, any number of handles.
+ *
+ * Stream ordering of POLAR_DEVICE buffers. The synchronous entry points enqueue on the handle's
+ * stream and return after that stream has drained, so results are complete on return. Inputs are
+ * the caller's business: by default the handle's stream is a private non-blocking stream that is
+ * ordered against NOTHING else, so device inputs must be complete (producer stream synchronised)
+ * before the call. A caller whose buffers are produced on a stream of its own makes that stream
+ * the handle's with polar_hip_set_stream(): the library's work is then ordered behind the
+ * producer like any other work on that stream, with no host synchronisation in between.
+ * polar_hip_decode_async() always runs on the stream passed to it.
  */
 #ifndef POLAR_HIP_H
 #define POLAR_HIP_H
@@ -71,8 +80,14 @@ void polar_hip_destroy(polar_hip_handle *h);
  * default: chosen per call from the batch size, the code size and the free device memory. */
 int polar_hip_configure(polar_hip_handle *h, int frames_per_wave, int lds_level, int max_waves);
 
+/* Stream the synchronous entry points enqueue on: use_callers != 0 selects `stream` (a
+ * hipStream_t, NULL = the null stream), 0 restores the handle's private stream. Work already
+ * enqueued through the handle is waited for first (it shares the handle's scratch). */
+int polar_hip_set_stream(polar_hip_handle *h, void *stream, int use_callers);
+
 /* Uploads a PolarCompiler program as the constant-memory instruction stream; returns a
- * program id >= 0. (polar_decoder.hh:131 takes the program per call; here it is resident.) */
+ * program id >= 0. (polar_decoder.hh:131 takes the program per call; here it is resident.) Loading the
+ * same bytes again returns the id of the resident copy. */
 int polar_hip_load_program(polar_hip_handle *h, const uint8_t *program, int length);
 
 /* PolarDecoder<TYPE,MAX_M>::operator()(message, codeword, program) polar_decoder.hh:131-464
@@ -80,7 +95,10 @@ int polar_hip_load_program(polar_hip_handle *h, const uint8_t *program, int leng
  * message: K x frames int8 decisions. `where` says whether both pointers are host or device. */
 int polar_hip_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, int where);
 /* Same, enqueued on `stream` (a hipStream_t) without synchronising; device pointers only. A
- * handle owns one scratch arena: keep its launches on one stream (any mix of programs). */
+ * handle owns one scratch arena: keep its launches on one stream (any mix of programs).
+ * The first launch of a program with a new wavefront shape uploads its instruction stream, and
+ * a launch that needs more scratch than the handle holds re-allocates it: both allocate (and
+ * the latter waits for the device). Launches after that only enqueue. */
 int polar_hip_decode_async(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, void *stream);
 
 /* PolarEncoder<TYPE,M>::operator() polar_encoder.hh:15-27 (systematic = 0) and

@@ -20,6 +20,7 @@ SYMBOLS = {
     "polar_hip_create": ([ctypes.POINTER(_vp), _i], _i),
     "polar_hip_destroy": ([_vp], None),
     "polar_hip_configure": ([_vp, _i, _i, _i], _i),
+    "polar_hip_set_stream": ([_vp, _vp, _i], _i),
     "polar_hip_load_program": ([_vp, _vp, _i], _i),
     "polar_hip_decode": ([_vp, _i, _vp, _vp, _sz, _i], _i),
     "polar_hip_decode_async": ([_vp, _i, _vp, _vp, _sz, _vp], _i),

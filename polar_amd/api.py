@@ -38,12 +38,6 @@ def _ptr(a):
     if hasattr(a, "data_ptr"):  # torch tensor
         if not a.is_contiguous():
             raise ValueError("buffers must be contiguous [elements][frames]")
-        if a.is_cuda:
-            # the library runs on its own stream: whatever torch still has queued on the
-            # tensor's producer stream must land first
-            import torch
-
-            torch.cuda.current_stream(a.device).synchronize()
         return ctypes.c_void_p(a.data_ptr()), DEVICE if a.is_cuda else HOST
     raise TypeError("expected a numpy array or a torch tensor")
 
@@ -104,6 +98,7 @@ class Session:
         _check(lib.polar_hip_create(ctypes.byref(h), device), "polar_hip_create")
         self._h = h
         self._programs = {}
+        self._stream = None  # None: the handle's private stream
 
     def close(self):
         if getattr(self, "_h", None):
@@ -115,6 +110,20 @@ class Session:
             self.close()
         except Exception:
             pass
+
+    def _order(self, *arrays):
+        """Device tensors are produced on torch's current stream: make it the handle's stream so
+        the library's work queues behind the producers with no host synchronisation
+        (include/polar_hip.h, stream ordering)."""
+        for a in arrays:
+            if a is not None and hasattr(a, "is_cuda") and a.is_cuda:
+                import torch
+
+                st = torch.cuda.current_stream(a.device).cuda_stream
+                if st != self._stream:
+                    _check(lib.polar_hip_set_stream(self._h, ctypes.c_void_p(st), 1), "polar_hip_set_stream")
+                    self._stream = st
+                return
 
     def configure(self, frames_per_wave=0, lds_level=0, max_waves=0):
         _check(lib.polar_hip_configure(self._h, frames_per_wave, lds_level, max_waves), "polar_hip_configure")
@@ -131,6 +140,7 @@ class Session:
     def count(self, counters, noisy, orig, decoded, message):
         """testbench.cc:185-192: counters[4] (int64) += awgn_errors, quantization_erasures,
         uncorrected_errors, ambiguity_erasures. Any of the two pairs may be None."""
+        self._order(counters, noisy, decoded)
         ptrs = [_ptr(x) for x in (counters, noisy, orig, decoded, message)]
         where = _where(*[w for _p, w in ptrs])
         n_code = int(noisy.numel() if hasattr(noisy, "numel") else noisy.size) if noisy is not None else 0
@@ -140,11 +150,13 @@ class Session:
     def random_message(self, message, seed, first_frame=0):
         """testbench.cc:126-127 with the counter-based generator of include/polar_hip.h:
         message[K][frames] = 1 - 2 * bit for global frames first_frame, first_frame + 1, ..."""
+        self._order(message)
         p, where = _ptr(message)
         _check(lib.polar_hip_random_message(self._h, p, int(message.shape[0]), _frames(message), int(seed), int(first_frame), where), "polar_hip_random_message")
 
     def channel(self, llr, codeword, snr_db, seed, first_frame=0):
         """testbench.cc:112-114, 151-165: BPSK + AWGN at Es/N0 = snr_db, LLR quantised to int8."""
+        self._order(llr)
         (pl, wl), (pc, wc) = _ptr(llr), _ptr(codeword)
         if tuple(llr.shape) != tuple(codeword.shape):
             raise PolarError(-1, "channel: llr and codeword must have the same shape")
@@ -155,6 +167,7 @@ class Session:
         device tensor), added to."""
         pid, _rows = self.load_program(program)
         fz = np.ascontiguousarray(frozen, dtype=np.uint8)
+        self._order(counters)
         pc, where = _ptr(counters)
         _check(lib.polar_hip_simulate(self._h, pid, fz.ctypes.data, int(level), int(bool(systematic)), float(snr_db), int(seed), int(first_frame), int(frames), pc, where), "polar_hip_simulate")
 
@@ -196,6 +209,7 @@ class PolarDecoder:
         n = 1 << int(np.asarray(program).ravel()[0])
         if codeword.shape[0] != n or (rows and (message.shape[0] < rows or _frames(message) != frames)):
             raise ValueError("buffer shapes do not match the program: codeword [%d][F], message [>=%d][F]" % (n, rows))
+        self.session._order(codeword)
         mp, mw = _ptr(message)
         cp, cw = _ptr(codeword)
         _check(lib.polar_hip_decode(self.session._h, pid, mp, cp, frames, _where(mw, cw)), "PolarDecoder")
@@ -219,6 +233,7 @@ class _Encoder:
         frozen = np.ascontiguousarray(frozen, np.uint8)
         if codeword.shape[0] != (1 << self.M) or frozen.size != (1 << self.M):
             raise ValueError("codeword / frozen must have N = %d rows" % (1 << self.M))
+        self.session._order(codeword)
         cp, cw = _ptr(codeword)
         mp, mw = _ptr(message)
         _check(lib.polar_hip_encode(self.session._h, self.systematic, cp, mp, frozen.ctypes.data, self.M, _frames(codeword), _where(cw, mw)), type(self).__name__)
@@ -230,6 +245,7 @@ class PolarEncoder(_Encoder):
     def extract_systematic(self, decoded, frozen):
         """testbench.cc:177-183: re-encode `decoded` and gather the information positions, in place."""
         frozen = np.ascontiguousarray(frozen, np.uint8)
+        self.session._order(decoded)
         dp, dw = _ptr(decoded)
         _check(lib.polar_hip_systematic_extract(self.session._h, dp, frozen.ctypes.data, self.M, _frames(decoded), dw), "extract_systematic")
 

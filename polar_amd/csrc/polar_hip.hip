@@ -312,8 +312,10 @@ struct LoadedProgram {
 struct polar_hip_handle {
 	int device = 0;
 	int cus = 0;
-	hipStream_t stream = nullptr;
+	hipStream_t own_stream = nullptr; // created with the handle
+	hipStream_t stream = nullptr;     // where the synchronous entry points enqueue: own_stream or the caller's (polar_hip_set_stream)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	std::map<const void *, int> occupancy; // resident workgroups per CU, per kernel variant
 	bool timed = false;
 	std::vector<LoadedProgram> programs;
 	DeviceBuffer scratch, stage_in, stage_out, enc_tmp, tables, counters, pad_in, pad_out;
@@ -392,7 +394,8 @@ extern "C" int polar_hip_create(polar_hip_handle **out, int device)
 	h->device = device;
 	h->cus = prop.multiProcessorCount;
 	HIP_TRY(hipSetDevice(device));
-	HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+	h->stream = h->own_stream;
 	HIP_TRY(hipEventCreate(&h->ev0));
 	HIP_TRY(hipEventCreate(&h->ev1));
 	*out = h;
@@ -405,6 +408,8 @@ extern "C" void polar_hip_destroy(polar_hip_handle *h)
 		return;
 	(void)hipSetDevice(h->device);
 	(void)hipStreamSynchronize(h->stream);
+	if (h->stream != h->own_stream)
+		(void)hipStreamSynchronize(h->own_stream);
 	for (auto &p : h->programs)
 		for (auto &d : p.dev)
 			(void)hipFree(d.second);
@@ -422,7 +427,7 @@ extern "C" void polar_hip_destroy(polar_hip_handle *h)
 	h->sim_dec.release();
 	(void)hipEventDestroy(h->ev0);
 	(void)hipEventDestroy(h->ev1);
-	(void)hipStreamDestroy(h->stream);
+	(void)hipStreamDestroy(h->own_stream);
 	delete h;
 }
 
@@ -445,10 +450,27 @@ extern "C" int polar_hip_configure(polar_hip_handle *h, int frames_per_wave, int
 	return POLAR_OK;
 }
 
+extern "C" int polar_hip_set_stream(polar_hip_handle *h, void *stream, int use_callers)
+{
+	if (!h)
+		return fail(POLAR_E_ARG, "polar_hip_set_stream: null handle");
+	int rc = use_device(h);
+	if (rc)
+		return rc;
+	hipStream_t next = use_callers ? (hipStream_t)stream : h->own_stream;
+	if (next != h->stream) // work already enqueued through the handle shares its scratch: let it drain
+		HIP_TRY(hipStreamSynchronize(h->stream));
+	h->stream = next;
+	return POLAR_OK;
+}
+
 extern "C" int polar_hip_load_program(polar_hip_handle *h, const uint8_t *program, int length)
 {
 	if (!h || !program)
 		return fail(POLAR_E_ARG, "polar_hip_load_program: null argument");
+	for (size_t i = 0; i < h->programs.size(); ++i) // the same byte-code again: the resident copy
+		if ((int)h->programs[i].bytes.size() == length && !memcmp(h->programs[i].bytes.data(), program, (size_t)length))
+			return (int)i;
 	LoadedProgram lp;
 	int err = translate_program(program, length, lp.host);
 	if (err)
@@ -560,7 +582,13 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 		msg = (uint8_t *)h->pad_out.p;
 	}
 	int per_cu = 0;
-	HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->fn, 64, 0));
+	auto occ = h->occupancy.find((const void *)v->fn);
+	if (occ == h->occupancy.end()) {
+		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->fn, 64, 0));
+		h->occupancy[(const void *)v->fn] = per_cu;
+	} else {
+		per_cu = occ->second;
+	}
 	if (per_cu < 1)
 		return fail(POLAR_E_HIP, "decode kernel does not fit on a CU");
 	size_t blocks = (size_t)per_cu * h->cus;

@@ -104,6 +104,100 @@ def test_wide_variants_full_size_digest(session, oracle, golden, fpw, rl):
         session.configure(0, 0, 0)
 
 
+@pytest.mark.parametrize("M,frames", [(16, 1 << 18), (16, (1 << 18) + 128 * 300 + 52), (20, 4096 + 96)])
+def test_bench_grid_parity(session, oracle, golden, M, frames):
+    """The exact path bench.py times: default variant pick on a batch that fills every resident
+    wavefront for several sweeps (N = 2^16: (128, 6), >= 2048 persistent workgroups, the XCD-aware
+    group order, the multi-GiB scratch arena), and a size that is not a multiple of the sweep. The
+    32 golden frames of the reference are tiled over the batch on the device: every 32-frame block
+    of the output must equal block 0, and block 0 must hash to the reference's digest."""
+    import polar_amd
+
+    meta, _ = golden
+    N = 1 << M
+    fro = _code(oracle, M)
+    prog = oracle.compile(fro, M)
+    dec = polar_amd.PolarDecoder(session)
+    out = torch.empty((N // 2, frames), dtype=torch.int8, device="cuda")
+    for k in [k for k in meta["decoder_digests"] if k["M"] == M]:
+        cw = oracle.encode(pm1_message(k["msg_seed"], N // 2, k["frames"]), fro, M, 1)
+        llr = family_llr(k["family"], k["llr_seed"], cw)
+        assert llr.shape[1] == 32
+        d = torch.from_numpy(llr).cuda()
+        wide = d.repeat(1, (frames + 31) // 32)[:, :frames].contiguous()
+        del d
+        out.fill_(77)
+        dec(out, wide, prog)
+        del wide
+        whole = frames // 32 * 32
+        blocks = out[:, :whole].view(N // 2, whole // 32, 32)
+        assert bool((blocks == blocks[:, :1, :]).all()), (M, frames, k["family"])
+        if frames > whole:
+            assert bool((out[:, whole:] == out[:, :frames - whole]).all())
+        assert "%016x" % fnv1a64(out[:, :32].contiguous().cpu().numpy()) == k["out_fnv"], (M, frames, k["family"])
+    del out
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("fpw,rl,waves", [(128, 6, 16), (128, 6, 8), (4, 11, 8), (32, 8, 24)])
+def test_persistent_sweeps_vs_oracle(session, oracle, fpw, rl, waves):
+    """Few resident wavefronts, many groups each: the `base += nb` sweep loop with stale LDS /
+    scratch planes and the erasure flags of the previous group, on inputs full of erasures."""
+    session.configure(fpw, rl, waves)
+    try:
+        for M, frames in ((8, 40 * fpw), (10, 37 * fpw + 5), (12, 5 * waves * fpw + 3)):
+            N = 1 << M
+            fro = _code(oracle, M)
+            prog = oracle.compile(fro, M)
+            cw = oracle.encode(pm1_message(M, N // 2, frames), fro, M, 0)
+            for fam in ("small", "uniform"):
+                llr = family_llr(fam, 3 * M + frames, cw)
+                assert (_decode(session, llr, prog, N // 2) == oracle.decode(llr, prog)).all(), (fpw, rl, waves, M, fam)
+    finally:
+        session.configure(0, 0, 0)
+
+
+def test_inputs_produced_on_another_stream(session, oracle):
+    """include/polar_hip.h, stream ordering: the producer's stream becomes the handle's stream, so a
+    decode queued right behind the kernels that write its input needs no host synchronisation."""
+    import polar_amd
+
+    M, frames = 12, 4096
+    N = 1 << M
+    fro = _code(oracle, M)
+    prog = oracle.compile(fro, M)
+    cw = oracle.encode(pm1_message(5, N // 2, frames), fro, M, 0)
+    llr = family_llr("awgn-1", 9, cw)
+    exp = oracle.decode(llr, prog)
+    src = torch.from_numpy(llr).cuda()
+    junk = torch.zeros((N, frames), dtype=torch.int8, device="cuda")
+    out = torch.zeros((N // 2, frames), dtype=torch.int8, device="cuda")
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    dec = polar_amd.PolarDecoder(session)
+    with torch.cuda.stream(side):
+        buf = junk
+        for _ in range(200):  # keep the stream busy so that the input lands late
+            buf = buf + 1
+        buf = buf * 0 + src
+        dec(out, buf, prog)
+    side.synchronize()
+    assert (out.cpu().numpy() == exp).all()
+    torch.cuda.synchronize()
+    dec(out, src, prog)  # back on the default stream
+    assert (out.cpu().numpy() == exp).all()
+
+
+def test_program_ids_are_deduplicated(session, oracle):
+    import polar_amd
+
+    fro = _code(oracle, 9)
+    prog = oracle.compile(fro, 9)
+    a = polar_amd.lib.polar_hip_load_program(session._h, prog.ctypes.data, prog.size)
+    b = polar_amd.lib.polar_hip_load_program(session._h, prog.ctypes.data, prog.size)
+    assert a >= 0 and a == b
+
+
 def test_decoder_every_opcode(session, oracle):
     rng = np.random.default_rng(11)
     seen = set()

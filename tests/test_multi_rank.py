@@ -70,3 +70,45 @@ def test_two_rank_counter_allreduce(oracle):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_bench_launcher_starts_the_ranks():
+    """`bench.py --gpus N` outside torchrun must start N ranks itself (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* plumbing), run the barrier-bracketed region and the counter all-reduce,
+    and print one line with n_gpus == N. Exercised here over gloo on the CPU."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--plumbing-only", "--frames", "1001"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2
+    assert d["counters"][0] == 1 + 2 and d["counters"][1] == 2002  # both ranks' shards, summed
+    # a world size that does not match --gpus is refused instead of printing n_gpus: 1
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--plumbing-only"],
+                       capture_output=True, text=True, timeout=120, env=env2)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_launcher_refuses_missing_gpus():
+    """Fewer visible devices than --gpus: non-zero exit with a clear message (this container has none)."""
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        import pytest
+
+        pytest.skip("needs a machine with fewer than 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
