@@ -19,6 +19,7 @@ ap.add_argument("--lds-level", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--snr", type=float, default=-1.0)
+ap.add_argument("--block-frozen", type=int, default=0, help="experiment: make the frozen set constant over 2^B-blocks (majority vote), so that no node below level B is left")
 a = ap.parse_args()
 import torch
 import polar_amd
@@ -31,6 +32,9 @@ if a.sweeps:
     a.frames = int(a.sweeps * per_cu * 256 * a.fpw)
 fro = np.zeros(N, np.uint8)
 polar_amd.PolarCodeConst0()(fro, a.M, N // 2, polar_amd.testbench_probability())
+if a.block_frozen:
+    b = 1 << a.block_frozen
+    fro = np.repeat((fro.reshape(-1, b).mean(axis=1) > 0.5).astype(np.uint8), b)
 prog = np.zeros(2 * N + 1, np.uint8)
 n = polar_amd.PolarCompiler()(prog, fro, a.M)
 prog = prog[:n].copy()
@@ -43,7 +47,8 @@ rows = max(1, min(N, (1 << 28) // a.frames))
 for r in range(0, N, rows):
     y = 1.0 + sigma * torch.randn((min(rows, N - r), a.frames), generator=g, device="cuda")
     llr[r:r + rows] = torch.clamp(torch.round(y * (2.0 / sigma**2)), -128, 127).to(torch.int8)
-out = torch.empty((N // 2, a.frames), dtype=torch.int8, device="cuda")
+Kc = int((fro == 0).sum())
+out = torch.empty((max(Kc, 1), a.frames), dtype=torch.int8, device="cuda")
 dec = polar_amd.PolarDecoder(sess)
 ms = []
 for _ in range(a.reps):
@@ -55,9 +60,9 @@ for _ in range(a.reps):
     print("  call wall %.2f ms, kernel %.2f ms" % (wall, ms[-1]), flush=True)
 best = min(ms)
 bad = 0
-for r in range(0, N // 2, 1024):
-    bad += int((out[r:r + 1024] != 1).sum())
-err = bad / float(out.numel())
+for r in range(0, min(Kc, N // 2), 1024):
+    bad += int((out[r:min(r + 1024, Kc)] != 1).sum())
+err = bad / float(max(1, min(Kc, N // 2) * a.frames))
 print("M %d frames %d fpw %d rl %d waves %d: kernel_ms %.2f  %.3f Mframes/s  %.1f Gbit/s info  frac %.4f  ber %.2e" % (
     a.M, a.frames, a.fpw, a.lds_level, a.waves, best, a.frames / best / 1e3, a.frames * (N // 2) / best / 1e6,
     a.frames * 1.5 * N / (best * 1e-3) / 8e12, err), flush=True)
