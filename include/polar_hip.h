@@ -101,6 +101,22 @@ int polar_hip_decode(polar_hip_handle *h, int program_id, int8_t *message, const
  * the latter waits for the device). Launches after that only enqueue. */
 int polar_hip_decode_async(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, void *stream);
 
+/* No counterpart in the reference: polar_hip_decode_async for callers that cannot allocate --
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc. The
+ * wavefront scratch arenas come from a file-scope device array of POLAR_STATIC_SCRATCH_BYTES
+ * (64 MiB, one copy per GPU, held until the process ends) instead of the handle's allocated arena,
+ * and the call makes no hipMalloc / hipFree / allocating library call: it only enqueues one kernel
+ * on `stream`. Limits, each rejected with POLAR_E_ARG and a message:
+ *   - frames must be a multiple of 32 and both pointers 16-byte aligned (no staging copies);
+ *   - one wavefront's arena, 10 * 2^level bytes, must fit the array: codes up to N = 2^22;
+ *     the array bounds the resident wavefronts (25 at N = 2^16), so big codes decode slowly here;
+ *   - the program must have been loaded with polar_hip_load_program (its instruction stream for
+ *     this entry point's kernel shape is uploaded then).
+ * Every call on one GPU shares that GPU's array: calls that overlap on one GPU race (also across
+ * handles and streams); serialise them. Nothing in the array has to start at zero: each
+ * wavefront writes what it reads, and stale contents of earlier calls are never read. */
+int polar_hip_decode_static(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, void *stream);
+
 /* PolarEncoder<TYPE,M>::operator() polar_encoder.hh:15-27 (systematic = 0) and
  * PolarSysEnc<TYPE,M>::operator() polar_encoder.hh:36-58 (systematic = 1).
  * message: K x frames, codeword: N x frames. */

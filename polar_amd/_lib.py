@@ -24,6 +24,7 @@ SYMBOLS = {
     "polar_hip_load_program": ([_vp, _vp, _i], _i),
     "polar_hip_decode": ([_vp, _i, _vp, _vp, _sz, _i], _i),
     "polar_hip_decode_async": ([_vp, _i, _vp, _vp, _sz, _vp], _i),
+    "polar_hip_decode_static": ([_vp, _i, _vp, _vp, _sz, _vp], _i),
     "polar_hip_encode": ([_vp, _i, _vp, _vp, _vp, _i, _sz, _i], _i),
     "polar_hip_systematic_extract": ([_vp, _vp, _vp, _i, _sz, _i], _i),
     "polar_hip_count": ([_vp, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _i], _i),

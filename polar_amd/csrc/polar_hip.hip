@@ -114,6 +114,23 @@ static const KernelVariant g_variants[] = {
 };
 #undef VARIANT
 
+static const KernelVariant *find_variant(int q, int rl)
+{
+	for (const KernelVariant &v : g_variants)
+		if (v.q == q && v.rl == rl)
+			return &v;
+	return nullptr;
+}
+
+// Scratch of polar_hip_decode_static(): the wavefront arenas of callers that may not allocate.
+// One copy per GPU, resident from code-object load until the process ends. Host code never uses
+// the symbol's name as an address: g_static_scratch[device] holds what hipGetSymbolAddress
+// returned with that device current (polar_hip_create).
+enum : size_t { STATIC_SCRATCH_BYTES = (size_t)POLAR_STATIC_SCRATCH_BYTES };
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+enum { MAX_DEVICES = 64, STATIC_Q = 8, STATIC_RL = 8 }; // the kernel shape of the static entry point: 32 frames per wavefront
+static void *g_static_scratch[MAX_DEVICES];
+
 // ---------------------------------------------------------------------------------------
 // encoder kernels
 // ---------------------------------------------------------------------------------------
@@ -330,6 +347,25 @@ static int use_device(polar_hip_handle *h)
 	return POLAR_OK;
 }
 
+// Device instruction stream of a loaded program for one wavefront shape (fusion depends on the
+// frame quads per wavefront and the variant's chain depth): fused and uploaded on first use.
+static int program_shape(const KernelVariant *v) { return v->q * 8 + v->chain_depth; }
+static int upload_shape(LoadedProgram &lp, const KernelVariant *v)
+{
+	const int shape = program_shape(v);
+	if (lp.dev.count(shape))
+		return POLAR_OK;
+	HostProgram hp;
+	if (translate_program(lp.bytes.data(), (int)lp.bytes.size(), hp, v->q, v->chain_depth))
+		return fail(POLAR_E_PROGRAM, "program translation failed");
+	DevOp *d = nullptr;
+	size_t bytes = hp.ops.size() * sizeof(DevOp);
+	HIP_TRY(hipMalloc((void **)&d, bytes));
+	HIP_TRY(hipMemcpy(d, hp.ops.data(), bytes, hipMemcpyHostToDevice));
+	lp.dev[shape] = d;
+	return POLAR_OK;
+}
+
 extern "C" const char *polar_hip_last_error(void)
 {
 	return g_error.c_str();
@@ -398,6 +434,17 @@ extern "C" int polar_hip_create(polar_hip_handle **out, int device)
 	h->stream = h->own_stream;
 	HIP_TRY(hipEventCreate(&h->ev0));
 	HIP_TRY(hipEventCreate(&h->ev1));
+	if (device < MAX_DEVICES && !g_static_scratch[device]) { // once per device, with that device current
+		void *ptr = nullptr;
+		HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+		g_static_scratch[device] = ptr;
+	}
+	{ // the static entry point must not meet a first-use query: resident workgroups of its kernel shape, now
+		const KernelVariant *sv = find_variant(STATIC_Q, STATIC_RL);
+		int per_cu = 0;
+		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sv->fn, 64, 0));
+		h->occupancy[(const void *)sv->fn] = per_cu;
+	}
 	*out = h;
 	return POLAR_OK;
 }
@@ -476,16 +523,12 @@ extern "C" int polar_hip_load_program(polar_hip_handle *h, const uint8_t *progra
 	if (err)
 		return fail(POLAR_E_PROGRAM, "polar_hip_load_program: malformed program (rule " + std::to_string(err) + ")");
 	lp.bytes.assign(program, program + length);
+	// the shape polar_hip_decode_static() runs is made resident now: that entry point may not allocate
+	int rc = use_device(h);
+	if (rc || (rc = upload_shape(lp, find_variant(STATIC_Q, STATIC_RL))))
+		return rc;
 	h->programs.push_back(lp);
 	return (int)h->programs.size() - 1;
-}
-
-static const KernelVariant *find_variant(int q, int rl)
-{
-	for (const KernelVariant &v : g_variants)
-		if (v.q == q && v.rl == rl)
-			return &v;
-	return nullptr;
 }
 
 // Bytes of scratch one wavefront needs: LLR levels above the LDS levels plus two partial-sum planes.
@@ -550,17 +593,10 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	const KernelVariant *v = pick_variant(h, lp.host.top, frames, budget);
 	if (!v)
 		return fail(POLAR_E_ARG, "no kernel variant for the configured (frames_per_wave, lds_level)");
-	const int shape = v->q * 8 + v->chain_depth;
-	if (!lp.dev.count(shape)) { // first use with this wavefront shape: fuse and upload
-		HostProgram hp;
-		if (translate_program(lp.bytes.data(), (int)lp.bytes.size(), hp, v->q, v->chain_depth))
-			return fail(POLAR_E_PROGRAM, "program translation failed");
-		DevOp *d = nullptr;
-		size_t bytes = hp.ops.size() * sizeof(DevOp);
-		HIP_TRY(hipMalloc((void **)&d, bytes));
-		HIP_TRY(hipMemcpy(d, hp.ops.data(), bytes, hipMemcpyHostToDevice));
-		lp.dev[shape] = d;
-	}
+	const int shape = program_shape(v);
+	int rc;
+	if ((rc = upload_shape(lp, v))) // first use with this wavefront shape: fuse and upload
+		return rc;
 	const size_t fpw = 4 * (size_t)v->q, n = (size_t)1 << lp.host.top, rows = lp.host.rows;
 	size_t groups = (frames + fpw - 1) / fpw;
 	if (groups > 0x7FFFFFFFu)
@@ -572,7 +608,6 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	const bool direct = padded == frames && (uintptr_t)codeword % 16 == 0 && (uintptr_t)message % 16 == 0;
 	const uint8_t *cw = (const uint8_t *)codeword;
 	uint8_t *msg = (uint8_t *)message;
-	int rc;
 	if (!direct) {
 		if ((rc = h->pad_in.reserve(n * padded)) || (rc = h->pad_out.reserve((rows ? rows : 1) * padded)))
 			return rc;
@@ -715,6 +750,62 @@ extern "C" int polar_hip_decode_async(polar_hip_handle *h, int program_id, int8_
 	if ((rc = use_device(h)))
 		return rc;
 	return launch_decode(h, program_id, message, codeword, frames, (hipStream_t)stream, false);
+}
+
+// No allocation on this path: fixed kernel shape (resident since polar_hip_load_program), arenas in
+// the file-scope `scratch` array through the per-device pointer taken at polar_hip_create, no
+// staging copies (so only whole groups and aligned rows), occupancy known since create.
+extern "C" int polar_hip_decode_static(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, void *stream)
+{
+	int rc = check_decode_args(h, program_id, message, codeword, frames);
+	if (rc)
+		return rc;
+	if ((rc = use_device(h)))
+		return rc;
+	if (!frames)
+		return POLAR_OK;
+	const KernelVariant *v = find_variant(STATIC_Q, STATIC_RL);
+	LoadedProgram &lp = h->programs[program_id];
+	const size_t fpw = 4 * (size_t)v->q;
+	if (frames % fpw || (uintptr_t)codeword % 16 || (uintptr_t)message % 16)
+		return fail(POLAR_E_ARG, "polar_hip_decode_static: frames must be a multiple of 32 and both buffers 16-byte aligned (this entry point cannot stage ragged batches: it does not allocate)");
+	void *arena = h->device < MAX_DEVICES ? g_static_scratch[h->device] : nullptr;
+	if (!arena)
+		return fail(POLAR_E_HIP, "polar_hip_decode_static: no static scratch on this device");
+	auto dev = lp.dev.find(program_shape(v));
+	auto occ = h->occupancy.find((const void *)v->fn);
+	if (dev == lp.dev.end() || occ == h->occupancy.end() || occ->second < 1)
+		return fail(POLAR_E_ARG, "polar_hip_decode_static: program not resident for this entry point");
+	const size_t groups = frames / fpw;
+	if (groups > 0x7FFFFFFFu)
+		return fail(POLAR_E_ARG, "too many frames for one call");
+	size_t blocks = (size_t)occ->second * h->cus;
+	DecodeArgs a;
+	a.scratch = nullptr;
+	a.block_dwords = 0;
+	if (lp.host.top > v->rl) {
+		const size_t per_wave = scratch_bytes_per_wave(v->q, lp.host.top);
+		const size_t fit = STATIC_SCRATCH_BYTES / per_wave;
+		if (fit < 1)
+			return fail(POLAR_E_ARG, "polar_hip_decode_static: one wavefront of this code needs " + std::to_string(per_wave) + " bytes of scratch, the static array holds " + std::to_string((size_t)STATIC_SCRATCH_BYTES) + " (codes up to N = 2^20)");
+		if (blocks > fit)
+			blocks = fit;
+		a.scratch = (u32 *)arena; // the pointer, never the symbol
+		a.block_dwords = per_wave / sizeof(u32);
+	}
+	if (blocks > groups)
+		blocks = groups;
+	a.prog = dev->second;
+	a.cw = (const uint8_t *)codeword;
+	a.msg = (uint8_t *)message;
+	a.stride = frames;
+	a.groups = (u32)groups;
+	a.top = lp.host.top;
+	a.prof = nullptr;
+	h->timed = false;
+	hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, a);
+	HIP_TRY(hipGetLastError());
+	return POLAR_OK;
 }
 
 extern "C" float polar_hip_last_decode_ms(polar_hip_handle *h)
