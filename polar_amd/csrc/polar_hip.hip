@@ -570,11 +570,14 @@ static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, siz
 {
 	if (h->cfg_frames_per_wave)
 		return find_variant(h->cfg_frames_per_wave / 4, h->cfg_lds_level);
+	// Measured (tools/gpu_sweep_pick.sh): a wavefront walks the program in about the same
+	// time whatever its width, so the widest group wins as soon as every resident wavefront has
+	// one; groups of at most 32 frames already pay off when half of the wavefronts have one.
 	const size_t resident = (size_t)8 * h->cus;
 	static const int family[][2] = {{32, 6}, {16, 7}, {8, 8}, {4, 9}, {2, 10}, {1, 11}};
 	for (const auto &f : family) {
 		size_t groups = (frames + 4 * f[0] - 1) / (4 * f[0]);
-		if (f[0] > 1 && groups < resident)
+		if (f[0] > 1 && groups < (f[0] <= 8 ? resident / 2 : resident))
 			continue;
 		if (f[0] > 1 && top > f[1] && !budget.fits(resident * scratch_bytes_per_wave(f[0], top)))
 			continue;
