@@ -1,7 +1,7 @@
 #!/bin/bash
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -k 10 600 python -u -m pytest tests/wip_no_alloc.py -x -q --timeout 300 --timeout-method thread > gpurun_out/noalloc.log 2>&1 || { tail -40 gpurun_out/noalloc.log; exit 1; }
+timeout -k 10 600 python -u -m pytest tests/test_zz_no_alloc.py -x -q --timeout 300 --timeout-method thread > gpurun_out/noalloc.log 2>&1 || { tail -40 gpurun_out/noalloc.log; exit 1; }
 tail -3 gpurun_out/noalloc.log
-timeout -k 10 900 python -u -m pytest tests tests/wip_no_alloc.py -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gputests.log 2>&1 || { tail -40 gpurun_out/gputests.log; exit 1; }
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/gputests.log 2>&1 || { tail -40 gpurun_out/gputests.log; exit 1; }
 tail -3 gpurun_out/gputests.log
