@@ -127,6 +127,16 @@ int polar_hip_encode(polar_hip_handle *h, int systematic, int8_t *codeword, cons
  * `decoded` (K x frames). */
 int polar_hip_systematic_extract(polar_hip_handle *h, int8_t *decoded, const uint8_t *frozen, int level, size_t frames, int where);
 
+/* The same step with a bit-packed result: instead of K x frames int8 symbols, one
+ * bit per symbol in two planes of K rows x 4 * ceil(frames / 32) bytes each (rows padded to whole
+ * dwords): sign_plane bit (f % 8) of byte (f / 8) of row k = 1 where the symbol of frame f is -1,
+ * erasure_plane (may be NULL) = 1 where it is 0. `decoded` (K x frames int8, the decoder's
+ * output) is not modified. 4x fewer bytes than int8 symbols (8x without the erasure plane). */
+int polar_hip_systematic_extract_packed(polar_hip_handle *h, uint8_t *sign_plane, uint8_t *erasure_plane, const int8_t *decoded,
+	const uint8_t *frozen, int level, size_t frames, int where);
+/* Inverse of the packing: symbols[rows][frames] (+1 / -1 / 0) from the two planes. */
+int polar_hip_unpack_symbols(polar_hip_handle *h, int8_t *symbols, const uint8_t *sign_plane, const uint8_t *erasure_plane, size_t rows, size_t frames, int where);
+
 /* Bench counters of testbench.cc:185-192 over flat symbol arrays:
  *   counters[0] += #(noisy*orig < 0)  (awgn_errors)      counters[1] += #(noisy == 0)  (quantization_erasures)
  *   counters[2] += #(decoded*message <= 0)  (uncorrected_errors, 0 counts as an error)

@@ -27,6 +27,8 @@ SYMBOLS = {
     "polar_hip_decode_static": ([_vp, _i, _vp, _vp, _sz, _vp], _i),
     "polar_hip_encode": ([_vp, _i, _vp, _vp, _vp, _i, _sz, _i], _i),
     "polar_hip_systematic_extract": ([_vp, _vp, _vp, _i, _sz, _i], _i),
+    "polar_hip_systematic_extract_packed": ([_vp, _vp, _vp, _vp, _vp, _i, _sz, _i], _i),
+    "polar_hip_unpack_symbols": ([_vp, _vp, _vp, _vp, _sz, _sz, _i], _i),
     "polar_hip_count": ([_vp, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _i], _i),
     "polar_hip_random_message": ([_vp, _vp, _sz, _sz, ctypes.c_uint64, ctypes.c_uint64, _i], _i),
     "polar_hip_channel": ([_vp, _vp, _vp, _sz, _sz, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, _i], _i),

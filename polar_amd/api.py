@@ -171,6 +171,12 @@ class Session:
         pc, where = _ptr(counters)
         _check(lib.polar_hip_simulate(self._h, pid, fz.ctypes.data, int(level), int(bool(systematic)), float(snr_db), int(seed), int(first_frame), int(frames), pc, where), "polar_hip_simulate")
 
+    def unpack_symbols(self, symbols, sign_plane, erasure_plane=None):
+        """symbols[rows][frames] (+1 / -1 / 0) from the bit planes of extract_systematic_packed."""
+        self._order(symbols)
+        (yp, yw), (sp, sw), (ep, ew) = _ptr(symbols), _ptr(sign_plane), _ptr(erasure_plane)
+        _check(lib.polar_hip_unpack_symbols(self._h, yp, sp, ep, int(symbols.shape[0]), _frames(symbols), _where(yw, sw, ew)), "polar_hip_unpack_symbols")
+
     def synchronize(self):
         _check(lib.polar_hip_synchronize(self._h), "polar_hip_synchronize")
 
@@ -248,6 +254,15 @@ class PolarEncoder(_Encoder):
         self.session._order(decoded)
         dp, dw = _ptr(decoded)
         _check(lib.polar_hip_systematic_extract(self.session._h, dp, frozen.ctypes.data, self.M, _frames(decoded), dw), "extract_systematic")
+
+
+    def extract_systematic_packed(self, sign_plane, erasure_plane, decoded, frozen):
+        """testbench.cc:177-183 with the bit-packed wire format of include/polar_hip.h: planes are
+        uint8 [K][4 * ceil(frames / 32)]; erasure_plane may be None; `decoded` is left alone."""
+        frozen = np.ascontiguousarray(frozen, np.uint8)
+        self.session._order(decoded)
+        (sp, sw), (ep, ew), (dp, dw) = _ptr(sign_plane), _ptr(erasure_plane), _ptr(decoded)
+        _check(lib.polar_hip_systematic_extract_packed(self.session._h, sp, ep, dp, frozen.ctypes.data, self.M, _frames(decoded), _where(sw, ew, dw)), "extract_systematic_packed")
 
 
 class PolarSysEnc(_Encoder):

@@ -3,7 +3,7 @@
 //   sc_decode_kernel   : batched SC decoder, one wavefront per group of 4*Q frames
 //                        (sc_core.hpp; replaces PolarDecoder::operator(), polar_decoder.hh:131)
 //   butterfly_kernel   : polar transform stages for the encoders (polar_encoder.hh:15-58)
-//   gather_rows_kernel : systematic extraction (testbench.cc:179-182)
+//   packed_transform_kernel : systematic extraction = re-encode + gather on bit-packed symbols (testbench.cc:177-183)
 //
 // Everything here fails loudly: there is no CPU fallback for any device entry point.
 #include <hip/hip_runtime.h>
@@ -195,14 +195,167 @@ __global__ void __launch_bounds__(256) butterfly_kernel(T *cw, const T *msg, con
 	}
 }
 
-// dst[r][col] = src[rows[r]][col]
-template <typename T>
-__global__ void __launch_bounds__(256) gather_rows_kernel(T *dst, const T *src, const int *rows, size_t cols)
+// ---------------------------------------------------------------------------------------
+// systematic post-processing (testbench.cc:177-183) on packed symbols
+// ---------------------------------------------------------------------------------------
+// Re-encoding the decoded u (PolarEncoder, polar_encoder.hh:15-27) and gathering the information
+// rows needs only the sign and the "is zero" bit of every symbol, so between the passes of the
+// transform a row of 32 frames is two dwords (neg, nz: bit f = frame 32*col + f) instead of 32
+// bytes. The first pass places the message rows (frozen positions are +1), the last pass writes
+// only the information rows -- as int8 symbols or as the two bit planes of the wire format.
+// Thread = one column of 32 frames x 2^C rows {row0 + (k << s0)} in registers, C stages per pass.
+struct PackedRow { u32 neg, nz; };
+
+// bit 7 of the four bytes of x -> bits 0..3
+__device__ __forceinline__ u32 gather_msb(u32 x) { return ((((x >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 15u; }
+// bits 0..3 -> bit 0 of the four bytes
+__device__ __forceinline__ u32 spread_lsb(u32 nib) { return (nib * 0x00204081u) & 0x01010101u; }
+
+// ragged batches / unaligned buffers: byte by byte, kept out of line so that the unrolled passes stay small
+__device__ __noinline__ PackedRow pack_symbols_slow(const uint8_t *row, size_t f0, size_t frames)
 {
-	const size_t colblocks = (cols + 255) / 256;
-	const size_t col = (blockIdx.x % colblocks) * 256 + threadIdx.x, r = blockIdx.x / colblocks;
-	if (col < cols)
-		dst[r * cols + col] = src[(size_t)rows[r] * cols + col];
+	PackedRow r = {0u, 0u};
+	for (int f = 0; f < 32; ++f)
+		if (f0 + f < frames) {
+			int v = (int8_t)row[f0 + f];
+			r.neg |= (u32)(v < 0) << f;
+			r.nz |= (u32)(v != 0) << f;
+		}
+	return r;
+}
+__device__ __noinline__ void unpack_symbols_slow(uint8_t *row, size_t f0, size_t frames, PackedRow r)
+{
+	for (int f = 0; f < 32; ++f)
+		if (f0 + f < frames)
+			row[f0 + f] = (r.nz >> f) & 1u ? ((r.neg >> f) & 1u ? 0xFFu : 0x01u) : 0x00u;
+}
+
+__device__ __forceinline__ PackedRow pack_symbols(const uint8_t *row, size_t f0, size_t frames, bool wide)
+{
+	PackedRow r = {0u, 0u};
+	if (wide) { // 32 frames, 16-byte aligned
+		const u32x4 *p = reinterpret_cast<const u32x4 *>(row + f0);
+		u32x4 a = p[0], b = p[1];
+		u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			r.neg |= gather_msb(w[k]) << (4 * k);
+			r.nz |= (gather_msb(zero_bytes(w[k])) ^ 15u) << (4 * k);
+		}
+	} else {
+		r = pack_symbols_slow(row, f0, frames);
+	}
+	return r;
+}
+
+__device__ __forceinline__ void unpack_symbols(uint8_t *row, size_t f0, size_t frames, bool wide, PackedRow r)
+{
+	if (wide) {
+		u32 w[8];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+			u32 ng = spread_lsb((r.neg >> (4 * k)) & 15u) * 0xFFu, nz = spread_lsb((r.nz >> (4 * k)) & 15u) * 0xFFu;
+			w[k] = nz & (ng | 0x01010101u);
+		}
+		u32x4 a, b;
+		a.x = w[0]; a.y = w[1]; a.z = w[2]; a.w = w[3];
+		b.x = w[4]; b.y = w[5]; b.z = w[6]; b.w = w[7];
+		u32x4 *p = reinterpret_cast<u32x4 *>(row + f0);
+		p[0] = a;
+		p[1] = b;
+	} else {
+		unpack_symbols_slow(row, f0, frames, r);
+	}
+}
+
+struct PackedPass {
+	PackedRow *tmp;        // [N][cols]
+	const uint8_t *msg;    // first pass: [K][frames] symbols
+	uint8_t *out;          // last pass: [K][frames] symbols, or null
+	u32 *out_sign, *out_eras; // last pass: [K][cols] bit planes (sign, erasure), or null
+	const int *src_row;    // [N]: message row of a code position, -1 = frozen
+	size_t frames, cols;
+	int level, s0, first, last, wide;
+};
+
+template <int C>
+__global__ void __launch_bounds__(256) packed_transform_kernel(PackedPass a)
+{
+	const int c = C; // stages in this pass (the host picks the instantiation)
+	const size_t item = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const size_t col = item % a.cols, j = item / a.cols;   // j enumerates rows with bits [s0, s0+c) clear
+	if (j >= ((size_t)1 << a.level) >> c)
+		return;
+	const size_t low = j & (((size_t)1 << a.s0) - 1);
+	const size_t row0 = ((j >> a.s0) << (a.s0 + c)) | low;
+	const size_t f0 = 32 * col;
+	const u32 valid = a.frames - f0 >= 32 ? ~0u : (1u << (a.frames - f0)) - 1u;
+	u32 neg[1 << C], nz[1 << C];
+#pragma unroll
+	for (int k = 0; k < (1 << C); ++k) {
+		{
+			const size_t row = row0 + ((size_t)k << a.s0);
+			PackedRow r;
+			if (a.first) {
+				int src = a.src_row[row];
+				if (src < 0) {
+					r.neg = 0u;
+					r.nz = valid;
+				} else {
+					r = pack_symbols(a.msg + (size_t)src * a.frames, f0, a.frames, a.wide);
+				}
+			} else {
+				r = a.tmp[row * a.cols + col];
+			}
+			neg[k] = r.neg;
+			nz[k] = r.nz;
+		}
+	}
+#pragma unroll
+	for (int t = 0; t < C; ++t) {
+		{
+#pragma unroll
+			for (int k = 0; k < (1 << C); ++k)
+				if (!(k & (1 << t))) { // qmul(a, b): sign xor, zero if either is zero
+					neg[k] ^= neg[k + (1 << t)];
+					nz[k] &= nz[k + (1 << t)];
+				}
+		}
+	}
+#pragma unroll
+	for (int k = 0; k < (1 << C); ++k) {
+		{
+			const size_t row = row0 + ((size_t)k << a.s0);
+			PackedRow r = {neg[k] & nz[k], nz[k]};
+			if (!a.last) {
+				a.tmp[row * a.cols + col] = r;
+				continue;
+			}
+			int dst = a.src_row[row];
+			if (dst < 0)
+				continue;
+			if (a.out)
+				unpack_symbols(a.out + (size_t)dst * a.frames, f0, a.frames, a.wide, r);
+			if (a.out_sign)
+				a.out_sign[(size_t)dst * a.cols + col] = r.neg;
+			if (a.out_eras)
+				a.out_eras[(size_t)dst * a.cols + col] = ~r.nz & valid;
+		}
+	}
+}
+
+// symbols[rows][frames] <- bit planes [rows][cols] (sign, erasure; erasure may be null)
+__global__ void __launch_bounds__(256) unpack_planes_kernel(uint8_t *symbols, const u32 *sign, const u32 *eras, size_t rows, size_t frames, size_t cols, int wide)
+{
+	const size_t item = (size_t)blockIdx.x * 256 + threadIdx.x;
+	const size_t col = item % cols, row = item / cols;
+	if (row >= rows)
+		return;
+	PackedRow r;
+	r.neg = sign[row * cols + col];
+	r.nz = eras ? ~eras[row * cols + col] : ~0u;
+	r.neg &= r.nz;
+	unpack_symbols(symbols + row * frames, 32 * col, frames, wide, r);
 }
 
 
@@ -930,31 +1083,66 @@ extern "C" int polar_hip_encode(polar_hip_handle *h, int systematic, int8_t *cod
 	return POLAR_OK;
 }
 
-// decoded (device, K x frames, u domain) -> message estimate: re-encode into tmp (N x frames)
-// and gather the information rows (testbench.cc:177-183). Tables must be current.
-static int extract_device(polar_hip_handle *h, int8_t *dev, int8_t *tmp, int level, int K, size_t frames)
+// decoded (device, K x frames, u domain) -> message estimate (testbench.cc:177-183): re-encode and
+// gather the information rows through packed passes; `tmp` holds N x ceil(frames / 32) PackedRows.
+// Output: int8 symbols in `out` (may alias `decoded`) and / or the two bit planes. Tables must be current.
+static const int PACK_C_MAX = 6;
+// stages per pass: spread evenly over the fewest passes of at most `cmax` stages
+static int pack_cmax()
 {
-	size_t n = (size_t)1 << level;
-	int rc = encode_device(h, 0, tmp, dev, level, frames);
-	if (rc)
-		return rc;
-	const int *info_pos = (const int *)h->tables.p + n;
-	bool wide = frames % 4 == 0 && (uintptr_t)dev % 4 == 0 && (uintptr_t)tmp % 4 == 0;
-	size_t cols = wide ? frames / 4 : frames, blocks = (size_t)K * ((cols + 255) / 256);
-	if (blocks > 0x7FFFFFFFu)
-		return fail(POLAR_E_ARG, "polar_hip_systematic_extract: too many frames for one call");
-	if (wide)
-		hipLaunchKernelGGL(gather_rows_kernel<u32>, dim3((unsigned)blocks), dim3(256), 0, h->stream, (u32 *)dev, (const u32 *)tmp, info_pos, cols);
-	else
-		hipLaunchKernelGGL(gather_rows_kernel<uint8_t>, dim3((unsigned)blocks), dim3(256), 0, h->stream, (uint8_t *)dev, (const uint8_t *)tmp, info_pos, cols);
-	HIP_TRY(hipGetLastError());
+	static int c = 0;
+	if (!c) {
+		const char *e = getenv("POLAR_HIP_PACK_C"); // experiments only
+		c = e ? atoi(e) : 5;
+		if (c < 1 || c > PACK_C_MAX)
+			c = 5;
+	}
+	return c;
+}
+static size_t packed_cols(size_t frames) { return (frames + 31) / 32; }
+static size_t packed_tmp_bytes(int level, size_t frames) { return level > pack_cmax() ? ((size_t)1 << level) * packed_cols(frames) * sizeof(PackedRow) : 0; }
+
+static int extract_device(polar_hip_handle *h, int8_t *out, u32 *out_sign, u32 *out_eras, const int8_t *decoded, void *tmp, int level, size_t frames)
+{
+	PackedPass a;
+	a.tmp = (PackedRow *)tmp;
+	a.msg = (const uint8_t *)decoded;
+	a.src_row = (const int *)h->tables.p;
+	a.frames = frames;
+	a.cols = packed_cols(frames);
+	a.level = level;
+	a.wide = frames % 32 == 0 && (uintptr_t)decoded % 16 == 0 && (uintptr_t)out % 16 == 0;
+	const int passes = (level + pack_cmax() - 1) / pack_cmax();
+	for (int s0 = 0, pass = 0; s0 < level; ++pass) {
+		int c = (level - s0 + (passes - pass) - 1) / (passes - pass); // what is left, spread over the passes left
+		a.s0 = s0;
+		a.first = s0 == 0;
+		a.last = s0 + c >= level;
+		a.out = a.last ? (uint8_t *)out : nullptr;
+		a.out_sign = a.last ? out_sign : nullptr;
+		a.out_eras = a.last ? out_eras : nullptr;
+		size_t items = (((size_t)1 << level) >> c) * a.cols, blocks = (items + 255) / 256;
+		if (blocks > 0x7FFFFFFFu)
+			return fail(POLAR_E_ARG, "polar_hip_systematic_extract: too many frames for one call");
+		switch (c) {
+		case 1: hipLaunchKernelGGL(packed_transform_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, h->stream, a); break;
+		case 2: hipLaunchKernelGGL(packed_transform_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, h->stream, a); break;
+		case 3: hipLaunchKernelGGL(packed_transform_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, h->stream, a); break;
+		case 4: hipLaunchKernelGGL(packed_transform_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, h->stream, a); break;
+		case 5: hipLaunchKernelGGL(packed_transform_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, h->stream, a); break;
+		default: hipLaunchKernelGGL(packed_transform_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, h->stream, a); break;
+		}
+		HIP_TRY(hipGetLastError());
+		s0 += c;
+	}
 	return POLAR_OK;
 }
 
-extern "C" int polar_hip_systematic_extract(polar_hip_handle *h, int8_t *decoded, const uint8_t *frozen, int level, size_t frames, int where)
+// shared body of polar_hip_systematic_extract and polar_hip_systematic_extract_packed
+static int extract_entry(polar_hip_handle *h, int8_t *out, uint8_t *sign, uint8_t *eras, const int8_t *decoded, const uint8_t *frozen, int level, size_t frames, int where, const char *who)
 {
 	if (!h || !frozen || level < 1 || level > MAX_LEVEL || (where != POLAR_HOST && where != POLAR_DEVICE))
-		return fail(POLAR_E_ARG, "polar_hip_systematic_extract: bad argument");
+		return fail(POLAR_E_ARG, std::string(who) + ": bad argument");
 	int rc = use_device(h), K = 0;
 	if (rc)
 		return rc;
@@ -964,22 +1152,81 @@ extern "C" int polar_hip_systematic_extract(polar_hip_handle *h, int8_t *decoded
 		return rc;
 	if (!K)
 		return POLAR_OK;
-	if (!decoded)
-		return fail(POLAR_E_ARG, "polar_hip_systematic_extract: null buffer");
-	size_t n = (size_t)1 << level;
-	if ((rc = h->enc_tmp.reserve(n * frames)))
+	if (!decoded || (!out && !sign))
+		return fail(POLAR_E_ARG, std::string(who) + ": null buffer");
+	if ((rc = h->enc_tmp.reserve(packed_tmp_bytes(level, frames) + 16)))
 		return rc;
-	int8_t *dev = decoded;
-	if (where == POLAR_HOST) {
-		if ((rc = h->stage_out.reserve((size_t)K * frames)))
+	const size_t sym_bytes = (size_t)K * frames, plane_bytes = (size_t)K * packed_cols(frames) * sizeof(u32);
+	if (where == POLAR_DEVICE) {
+		if (((uintptr_t)sign | (uintptr_t)eras) % 4)
+			return fail(POLAR_E_ARG, std::string(who) + ": bit planes must be 4-byte aligned");
+		if ((rc = extract_device(h, out, (u32 *)sign, (u32 *)eras, decoded, h->enc_tmp.p, level, frames)))
 			return rc;
-		dev = (int8_t *)h->stage_out.p;
-		HIP_TRY(hipMemcpyAsync(dev, decoded, (size_t)K * frames, hipMemcpyHostToDevice, h->stream));
+		HIP_TRY(hipStreamSynchronize(h->stream));
+		return POLAR_OK;
 	}
-	if ((rc = extract_device(h, dev, (int8_t *)h->enc_tmp.p, level, K, frames)))
+	if ((rc = h->stage_out.reserve(sym_bytes)) || (rc = h->stage_in.reserve(2 * plane_bytes + 16)))
 		return rc;
+	int8_t *dev = (int8_t *)h->stage_out.p;
+	u32 *dsign = sign ? (u32 *)h->stage_in.p : nullptr, *deras = eras ? (u32 *)((uint8_t *)h->stage_in.p + plane_bytes) : nullptr;
+	HIP_TRY(hipMemcpyAsync(dev, decoded, sym_bytes, hipMemcpyHostToDevice, h->stream));
+	if ((rc = extract_device(h, out ? dev : nullptr, dsign, deras, dev, h->enc_tmp.p, level, frames)))
+		return rc;
+	if (out)
+		HIP_TRY(hipMemcpyAsync(out, dev, sym_bytes, hipMemcpyDeviceToHost, h->stream));
+	if (sign)
+		HIP_TRY(hipMemcpyAsync(sign, dsign, plane_bytes, hipMemcpyDeviceToHost, h->stream));
+	if (eras)
+		HIP_TRY(hipMemcpyAsync(eras, deras, plane_bytes, hipMemcpyDeviceToHost, h->stream));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return POLAR_OK;
+}
+
+extern "C" int polar_hip_systematic_extract(polar_hip_handle *h, int8_t *decoded, const uint8_t *frozen, int level, size_t frames, int where)
+{
+	return extract_entry(h, decoded, nullptr, nullptr, decoded, frozen, level, frames, where, "polar_hip_systematic_extract");
+}
+
+extern "C" int polar_hip_systematic_extract_packed(polar_hip_handle *h, uint8_t *sign_plane, uint8_t *erasure_plane, const int8_t *decoded, const uint8_t *frozen, int level, size_t frames, int where)
+{
+	if (!sign_plane)
+		return fail(POLAR_E_ARG, "polar_hip_systematic_extract_packed: null sign plane");
+	return extract_entry(h, nullptr, sign_plane, erasure_plane, decoded, frozen, level, frames, where, "polar_hip_systematic_extract_packed");
+}
+
+extern "C" int polar_hip_unpack_symbols(polar_hip_handle *h, int8_t *symbols, const uint8_t *sign_plane, const uint8_t *erasure_plane, size_t rows, size_t frames, int where)
+{
+	if (!h || (where != POLAR_HOST && where != POLAR_DEVICE) || (rows && frames && (!symbols || !sign_plane)))
+		return fail(POLAR_E_ARG, "polar_hip_unpack_symbols: bad argument");
+	int rc = use_device(h);
+	if (rc)
+		return rc;
+	if (!rows || !frames)
+		return POLAR_OK;
+	const size_t cols = packed_cols(frames), plane_bytes = rows * cols * sizeof(u32), sym_bytes = rows * frames;
+	uint8_t *dsym = (uint8_t *)symbols;
+	const u32 *dsign = (const u32 *)sign_plane, *deras = (const u32 *)erasure_plane;
+	if (where == POLAR_HOST) {
+		if ((rc = h->stage_out.reserve(sym_bytes)) || (rc = h->stage_in.reserve(2 * plane_bytes + 16)))
+			return rc;
+		dsym = (uint8_t *)h->stage_out.p;
+		HIP_TRY(hipMemcpyAsync(h->stage_in.p, sign_plane, plane_bytes, hipMemcpyHostToDevice, h->stream));
+		dsign = (const u32 *)h->stage_in.p;
+		if (erasure_plane) {
+			HIP_TRY(hipMemcpyAsync((uint8_t *)h->stage_in.p + plane_bytes, erasure_plane, plane_bytes, hipMemcpyHostToDevice, h->stream));
+			deras = (const u32 *)((uint8_t *)h->stage_in.p + plane_bytes);
+		}
+	} else if (((uintptr_t)sign_plane | (uintptr_t)erasure_plane) % 4) {
+		return fail(POLAR_E_ARG, "polar_hip_unpack_symbols: bit planes must be 4-byte aligned");
+	}
+	size_t blocks = (rows * cols + 255) / 256;
+	if (blocks > 0x7FFFFFFFu)
+		return fail(POLAR_E_ARG, "polar_hip_unpack_symbols: too many symbols for one call");
+	int wide = frames % 32 == 0 && (uintptr_t)dsym % 16 == 0;
+	hipLaunchKernelGGL(unpack_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, h->stream, dsym, dsign, deras, rows, frames, cols, wide);
+	HIP_TRY(hipGetLastError());
 	if (where == POLAR_HOST)
-		HIP_TRY(hipMemcpyAsync(decoded, dev, (size_t)K * frames, hipMemcpyDeviceToHost, h->stream));
+		HIP_TRY(hipMemcpyAsync(symbols, dsym, sym_bytes, hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	return POLAR_OK;
 }
@@ -1122,7 +1369,7 @@ extern "C" int polar_hip_simulate(polar_hip_handle *h, int program_id, const uin
 	if (chunk > frames)
 		chunk = frames;
 	if (frames) {
-		if ((rc = h->sim_cw.reserve(n * chunk)) || (rc = h->sim_llr.reserve(n * chunk)) || (rc = h->sim_msg.reserve((size_t)(K ? K : 1) * chunk)) || (rc = h->sim_dec.reserve((size_t)(K ? K : 1) * chunk)))
+		if ((rc = h->sim_cw.reserve(n * chunk > packed_tmp_bytes(level, chunk) ? n * chunk : packed_tmp_bytes(level, chunk))) || (rc = h->sim_llr.reserve(n * chunk)) || (rc = h->sim_msg.reserve((size_t)(K ? K : 1) * chunk)) || (rc = h->sim_dec.reserve((size_t)(K ? K : 1) * chunk)))
 			return rc;
 	}
 	int8_t *cw = (int8_t *)h->sim_cw.p, *llr = (int8_t *)h->sim_llr.p, *msg = (int8_t *)h->sim_msg.p, *dec = (int8_t *)h->sim_dec.p;
@@ -1139,7 +1386,7 @@ extern "C" int polar_hip_simulate(polar_hip_handle *h, int program_id, const uin
 			return rc;
 		if ((rc = launch_decode(h, program_id, dec, llr, f, h->stream, false)))
 			return rc;
-		if (systematic && K && (rc = extract_device(h, dec, cw, level, K, f)))
+		if (systematic && K && (rc = extract_device(h, dec, nullptr, nullptr, dec, cw, level, f)))
 			return rc;
 		if (K && (rc = count_device(h, c, nullptr, nullptr, 0, (const uint8_t *)dec, (const uint8_t *)msg, (size_t)K * f)))
 			return rc;

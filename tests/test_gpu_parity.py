@@ -286,6 +286,55 @@ def test_systematic_chain(session, oracle):
                 assert (dec == msg).all()
 
 
+def test_packed_systematic_extract(session, oracle):
+    """the fused re-encode + gather with the bit-packed result; unpacking the planes
+    must give oracle.systematic_extract bit for bit, erasures included, ragged and aligned frame
+    counts, host and device buffers, codes below and above one pass of the transform."""
+    import polar_amd
+
+    for M, frames in ((3, 5), (6, 64), (7, 33), (10, 100), (12, 64), (13, 96), (14, 32)):
+        N = 1 << M
+        fro = _code(oracle, M)
+        K = int((fro == 0).sum())
+        prog = oracle.compile(fro, M)
+        cw = oracle.encode(pm1_message(M + 40, K, frames), fro, M, 1)
+        for fam in ("awgn-1", "uniform"):
+            llr = family_llr(fam, 17 + M, cw)
+            dec = oracle.decode(llr, prog)  # u-domain decisions, with erasures for "uniform"
+            exp = oracle.systematic_extract(dec, fro, M)
+            cols = (frames + 31) // 32
+            enc = polar_amd.PolarEncoder(M, session)
+            inplace = dec.copy()
+            enc.extract_systematic(inplace, fro)
+            assert (inplace == exp).all(), (M, frames, fam)
+            sign = np.full((K, 4 * cols), 0xAA, np.uint8)
+            eras = np.full((K, 4 * cols), 0x55, np.uint8)
+            keep = dec.copy()
+            enc.extract_systematic_packed(sign, eras, keep, fro)
+            assert (keep == dec).all()
+            bits = np.unpackbits(sign, axis=1, bitorder="little")[:, :frames]
+            ebits = np.unpackbits(eras, axis=1, bitorder="little")[:, :frames]
+            assert (bits == (exp < 0)).all() and (ebits == (exp == 0)).all(), (M, frames, fam)
+            assert not np.unpackbits(eras, axis=1, bitorder="little")[:, frames:].any()  # padding bits are clear
+            back = np.zeros_like(exp)
+            session.unpack_symbols(back, sign, eras)
+            assert (back == exp).all()
+            # device buffers
+            d_dec = torch.from_numpy(dec).cuda()
+            d_sign = torch.zeros((K, 4 * cols), dtype=torch.uint8, device="cuda")
+            d_eras = torch.zeros_like(d_sign)
+            enc.extract_systematic_packed(d_sign, d_eras, d_dec, fro)
+            d_back = torch.zeros((K, frames), dtype=torch.int8, device="cuda")
+            session.unpack_symbols(d_back, d_sign, d_eras)
+            assert (d_back.cpu().numpy() == exp).all()
+            enc.extract_systematic(d_dec, fro)
+            assert (d_dec.cpu().numpy() == exp).all()
+            if fam == "awgn-1" and M >= 10:
+                sign_only = np.zeros((K, 4 * cols), np.uint8)
+                enc.extract_systematic_packed(sign_only, None, keep, fro)
+                assert (sign_only == sign).all()
+
+
 def test_full_size_properties(session, oracle):
     """N = 2^16 at batch sizes the oracle cannot follow: noise-free and mildly noisy systematic
     codewords must decode to the transmitted message; a checksum over a subset is compared
