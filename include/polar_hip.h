@@ -58,6 +58,15 @@ const char *polar_hip_last_error(void);
 
 /* PolarCodeConst0<MAX_M>::operator() polar_freezer.hh:49-61. Returns POLAR_OK. */
 int polar_code_const0(uint8_t *frozen, int level, int K, long double erasure_probability);
+/* The same, and *ambiguous (may be NULL) = 1 when the K-th and (K+1)-th most reliable channels
+ * have exactly the same erasure probability: the reference leaves their order to
+ * std::nth_element (polar_freezer.hh:56), so its frozen set is implementation-defined there;
+ * this library gives the lower index the information bit. 0 otherwise. */
+int polar_code_const0_ex(uint8_t *frozen, int level, int K, long double erasure_probability, int *ambiguous);
+/* `count` constructions of one (level, K), one per erasure probability -- a list of design SNRs
+ * (testbench.cc:74-88 per SNR point) -- on the host cores in parallel.
+ * frozen: count x N bytes; ambiguous: count ints or NULL. */
+int polar_code_const0_batch(uint8_t *frozen, int *ambiguous, int level, int K, const long double *erasure_probability, int count);
 /* PolarFreezer::operator() polar_freezer.hh:23-31. Returns K (>= 0). */
 int polar_freezer(uint8_t *frozen, int level, long double erasure_probability, long double freezing_threshold);
 /* PolarCompiler::operator() polar_compiler.hh:51-58. `program` needs room for 2N+1 bytes in
@@ -89,6 +98,14 @@ int polar_hip_set_stream(polar_hip_handle *h, void *stream, int use_callers);
  * program id >= 0. (polar_decoder.hh:131 takes the program per call; here it is resident.) Loading the
  * same bytes again returns the id of the resident copy. */
 int polar_hip_load_program(polar_hip_handle *h, const uint8_t *program, int length);
+
+/* Code cache of the handle: PolarCodeConst0 + PolarCompiler + polar_hip_load_program
+ * for (level, K, erasure_probability), done on the first request of that key only (testbench.cc:74-98
+ * per design point). Returns the resident program id; the out-pointers (each may be NULL) receive
+ * the frozen set (N bytes) and the program, owned by the handle until polar_hip_destroy, the
+ * program length, and the ambiguity flag of polar_code_const0_ex. */
+int polar_hip_code(polar_hip_handle *h, int level, int K, long double erasure_probability, const uint8_t **frozen, const uint8_t **program,
+	int *program_length, int *ambiguous);
 
 /* PolarDecoder<TYPE,MAX_M>::operator()(message, codeword, program) polar_decoder.hh:131-464
  * for `frames` frames at once. codeword: N x frames int8 LLRs (not modified);
@@ -174,8 +191,9 @@ int polar_hip_simulate(polar_hip_handle *h, int program_id, const uint8_t *froze
 /* Blocks until all work enqueued through this handle has finished. */
 int polar_hip_synchronize(polar_hip_handle *h);
 
-/* Milliseconds the GPU spent in the decode kernel of the last polar_hip_decode call
- * (HIP events on the launch stream), or a negative error. */
+/* Milliseconds the GPU spent in the decode kernel of the last polar_hip_decode call, or of the
+ * last chunk of the last polar_hip_simulate call (HIP events on the launch stream; the region
+ * testbench.cc:170-175 times), or a negative error. */
 float polar_hip_last_decode_ms(polar_hip_handle *h);
 
 #ifdef __cplusplus

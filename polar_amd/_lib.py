@@ -14,6 +14,8 @@ _ld = ctypes.c_longdouble
 SYMBOLS = {
     "polar_hip_last_error": ([], ctypes.c_char_p),
     "polar_code_const0": ([_vp, _i, _i, _ld], _i),
+    "polar_code_const0_ex": ([_vp, _i, _i, _ld, ctypes.POINTER(_i)], _i),
+    "polar_code_const0_batch": ([_vp, _vp, _i, _i, _vp, _i], _i),
     "polar_freezer": ([_vp, _i, _ld, _ld], _i),
     "polar_compile": ([_vp, _vp, _i], _i),
     "polar_program_rows": ([_vp, _i], _i),
@@ -22,6 +24,7 @@ SYMBOLS = {
     "polar_hip_configure": ([_vp, _i, _i, _i], _i),
     "polar_hip_set_stream": ([_vp, _vp, _i], _i),
     "polar_hip_load_program": ([_vp, _vp, _i], _i),
+    "polar_hip_code": ([_vp, _i, _i, _ld, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
     "polar_hip_decode": ([_vp, _i, _vp, _vp, _sz, _i], _i),
     "polar_hip_decode_async": ([_vp, _i, _vp, _vp, _sz, _vp], _i),
     "polar_hip_decode_static": ([_vp, _i, _vp, _vp, _sz, _vp], _i),

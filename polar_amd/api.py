@@ -65,6 +65,23 @@ class PolarCodeConst0:
         _check(lib.polar_code_const0(frozen_bits.ctypes.data, level, K, erasure_probability), "PolarCodeConst0")
 
 
+    def ambiguous(self, frozen_bits, level, K, erasure_probability=0.36787944117144233):
+        """The construction, returning whether the K-boundary fell on an exact tie (the reference's
+        std::nth_element leaves that case implementation-defined, polar_freezer.hh:56)."""
+        amb = ctypes.c_int(0)
+        _check(lib.polar_code_const0_ex(frozen_bits.ctypes.data, level, K, erasure_probability, ctypes.byref(amb)), "PolarCodeConst0")
+        return bool(amb.value)
+
+    def batch(self, level, K, erasure_probabilities):
+        """One frozen set per erasure probability (design SNR), built on the host cores in parallel.
+        Returns (frozen [count][N] uint8, ambiguous [count] bool)."""
+        ps = (ctypes.c_longdouble * len(erasure_probabilities))(*erasure_probabilities)
+        out = np.zeros((len(erasure_probabilities), 1 << level), np.uint8)
+        amb = np.zeros(len(erasure_probabilities), np.int32)
+        _check(lib.polar_code_const0_batch(out.ctypes.data, amb.ctypes.data, level, K, ctypes.cast(ps, ctypes.c_void_p), len(erasure_probabilities)), "PolarCodeConst0.batch")
+        return out, amb.astype(bool)
+
+
 class PolarFreezer:
     """polar_freezer.hh:11-32. __call__(frozen, level, erasure_probability=0.5, threshold=0.5) -> K."""
 
@@ -136,6 +153,17 @@ class Session:
             rows = _check(lib.polar_program_rows(program.ctypes.data, program.size), "polar_program_rows")
             self._programs[key] = (pid, rows)
         return self._programs[key]
+
+    def code(self, level, K, erasure_probability):
+        """Cached (level, K, p) -> (frozen, program, ambiguous): construction, compilation and upload
+        happen once per key inside the handle (include/polar_hip.h, polar_hip_code)."""
+        fz, pr, n, amb = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(0), ctypes.c_int(0)
+        pid = _check(lib.polar_hip_code(self._h, level, K, erasure_probability, ctypes.byref(fz), ctypes.byref(pr), ctypes.byref(n), ctypes.byref(amb)), "polar_hip_code")
+        frozen = np.ctypeslib.as_array(ctypes.cast(fz, ctypes.POINTER(ctypes.c_uint8)), shape=(1 << level,)).copy()
+        program = np.ctypeslib.as_array(ctypes.cast(pr, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value,)).copy()
+        rows = _check(lib.polar_program_rows(program.ctypes.data, program.size), "polar_program_rows")
+        self._programs[program.tobytes()] = (pid, rows)
+        return frozen, program, bool(amb.value)
 
     def count(self, counters, noisy, orig, decoded, message):
         """testbench.cc:185-192: counters[4] (int64) += awgn_errors, quantization_erasures,

@@ -33,7 +33,10 @@ inline void bec_channels(std::vector<long double> &pe, int level, long double p)
 	}
 }
 
-inline void code_const0(uint8_t *frozen, int level, int K, long double p)
+// Returns 1 when the choice was ambiguous: the K-th and (K+1)-th most reliable channels have
+// exactly the same erasure probability, so which of them carries information is left to
+// std::nth_element in the reference (polar_freezer.hh:56, no tie-break); here the lower index wins.
+inline int code_const0(uint8_t *frozen, int level, int K, long double p)
 {
 	size_t n = (size_t)1 << level;
 	std::vector<long double> pe;
@@ -45,6 +48,12 @@ inline void code_const0(uint8_t *frozen, int level, int K, long double p)
 		std::nth_element(order.begin(), order.begin() + K, order.end(), better);
 	for (size_t i = 0; i < n; ++i)
 		frozen[order[i]] = i >= (size_t)K;
+	if (K <= 0 || (size_t)K >= n)
+		return 0;
+	long double worst_info = pe[order[0]]; // nth_element leaves the first K unordered
+	for (int i = 1; i < K; ++i)
+		worst_info = std::max(worst_info, pe[order[i]]);
+	return worst_info == pe[order[K]];
 }
 
 inline int freezer(uint8_t *frozen, int level, long double p, long double threshold)

@@ -14,6 +14,7 @@
 
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/polar_hip.h"
@@ -488,6 +489,16 @@ struct polar_hip_handle {
 	std::map<const void *, int> occupancy; // resident workgroups per CU, per kernel variant
 	bool timed = false;
 	std::vector<LoadedProgram> programs;
+	struct CachedCode {
+		std::vector<uint8_t> frozen, program;
+		int program_id, ambiguous;
+	};
+	struct CodeKey {
+		int level, K;
+		long double p;
+		bool operator<(const CodeKey &o) const { return level != o.level ? level < o.level : K != o.K ? K < o.K : p < o.p; }
+	};
+	std::map<CodeKey, CachedCode> codes; // polar_hip_code: (level, K, p) -> frozen set, program, resident id
 	DeviceBuffer scratch, stage_in, stage_out, enc_tmp, tables, counters, pad_in, pad_out;
 	DeviceBuffer sim_cw, sim_llr, sim_msg, sim_dec; // polar_hip_simulate's chunk
 	std::vector<uint8_t> frozen_cache; // frozen set the device tables were built from
@@ -526,11 +537,44 @@ extern "C" const char *polar_hip_last_error(void)
 
 // ---- host-side construction ----
 
-extern "C" int polar_code_const0(uint8_t *frozen, int level, int K, long double erasure_probability)
+extern "C" int polar_code_const0_ex(uint8_t *frozen, int level, int K, long double erasure_probability, int *ambiguous)
 {
 	if (!frozen || level < 0 || level > MAX_LEVEL || K < 0 || K > (1 << level))
 		return fail(POLAR_E_ARG, "polar_code_const0: bad argument");
-	code_const0(frozen, level, K, erasure_probability);
+	int amb = code_const0(frozen, level, K, erasure_probability);
+	if (ambiguous)
+		*ambiguous = amb;
+	return POLAR_OK;
+}
+
+extern "C" int polar_code_const0(uint8_t *frozen, int level, int K, long double erasure_probability)
+{
+	return polar_code_const0_ex(frozen, level, K, erasure_probability, nullptr);
+}
+
+extern "C" int polar_code_const0_batch(uint8_t *frozen, int *ambiguous, int level, int K, const long double *erasure_probability, int count)
+{
+	if (!frozen || !erasure_probability || count < 0 || level < 0 || level > MAX_LEVEL || K < 0 || K > (1 << level))
+		return fail(POLAR_E_ARG, "polar_code_const0_batch: bad argument");
+	const size_t n = (size_t)1 << level;
+	unsigned hw = std::thread::hardware_concurrency();
+	int workers = (int)(hw ? (hw > 16 ? 16 : hw) : 4);
+	if (workers > count)
+		workers = count;
+	auto work = [&](int w) {
+		for (int i = w; i < count; i += workers) {
+			int amb = code_const0(frozen + (size_t)i * n, level, K, erasure_probability[i]);
+			if (ambiguous)
+				ambiguous[i] = amb;
+		}
+	};
+	std::vector<std::thread> pool;
+	for (int w = 1; w < workers; ++w)
+		pool.emplace_back(work, w);
+	if (workers > 0)
+		work(0);
+	for (auto &t : pool)
+		t.join();
 	return POLAR_OK;
 }
 
@@ -718,6 +762,41 @@ struct ScratchBudget {
 		return cap;
 	}
 };
+
+extern "C" int polar_hip_load_program(polar_hip_handle *h, const uint8_t *program, int length);
+
+extern "C" int polar_hip_code(polar_hip_handle *h, int level, int K, long double erasure_probability, const uint8_t **frozen, const uint8_t **program, int *program_length, int *ambiguous)
+{
+	if (!h || level < 1 || level > MAX_LEVEL || K < 0 || K > (1 << level) || !(erasure_probability >= 0) || !(erasure_probability <= 1))
+		return fail(POLAR_E_ARG, "polar_hip_code: bad argument");
+	polar_hip_handle::CodeKey key = {level, K, erasure_probability};
+	auto it = h->codes.find(key);
+	if (it == h->codes.end()) {
+		polar_hip_handle::CachedCode c;
+		const size_t n = (size_t)1 << level;
+		c.frozen.resize(n);
+		c.ambiguous = code_const0(c.frozen.data(), level, K, erasure_probability);
+		c.program.resize(2 * n + 1);
+		ProgramBuilder b;
+		int len = b.run(c.program.data(), c.frozen.data(), level);
+		if (len < 0)
+			return fail(POLAR_E_PROGRAM, "polar_hip_code: the frozen set of this (level, K, p) cannot be compiled (reference asserts level > 0)");
+		c.program.resize((size_t)len);
+		c.program_id = polar_hip_load_program(h, c.program.data(), len);
+		if (c.program_id < 0)
+			return c.program_id;
+		it = h->codes.emplace(key, std::move(c)).first;
+	}
+	if (frozen)
+		*frozen = it->second.frozen.data();
+	if (program)
+		*program = it->second.program.data();
+	if (program_length)
+		*program_length = (int)it->second.program.size();
+	if (ambiguous)
+		*ambiguous = it->second.ambiguous;
+	return it->second.program_id;
+}
 
 static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, size_t frames, ScratchBudget &budget)
 {
@@ -1384,7 +1463,7 @@ extern "C" int polar_hip_simulate(polar_hip_handle *h, int program_id, const uin
 			return rc;
 		if ((rc = count_device(h, c, (const uint8_t *)llr, (const uint8_t *)cw, n * f, nullptr, nullptr, 0)))
 			return rc;
-		if ((rc = launch_decode(h, program_id, dec, llr, f, h->stream, false)))
+		if ((rc = launch_decode(h, program_id, dec, llr, f, h->stream, true))) // timed: polar_hip_last_decode_ms reports the last chunk
 			return rc;
 		if (systematic && K && (rc = extract_device(h, dec, nullptr, nullptr, dec, cw, level, f)))
 			return rc;

@@ -440,6 +440,36 @@ def test_simulate_matches_the_step_by_step_chain(session, oracle):
         assert d.cpu().numpy().tolist() == got.tolist()
 
 
+def test_code_cache_and_sweep_harness(session, oracle):
+    """the handle's (level, K, p) cache returns the reference's construction and one
+    resident program per key; the sweep harness on top of polar_hip_simulate prints the reference's
+    four columns and finds the waterfall where ber_log.png (README.md:24) has it for N = 2^12..2^14:
+    errors at -3 dB, none at +1 dB. (The reference's own random stream cannot be reproduced, so the
+    curve itself is unpinned; every counter behind it is pinned by test_simulate_*.)"""
+    import io
+
+    from polar_amd.sweep import ber_sweep, design_probability, design_snr
+
+    M = 12
+    N = 1 << M
+    p = design_probability(design_snr())
+    fro, prog, amb = session.code(M, N // 2, p)
+    ofro, oamb = oracle.const0(M, N // 2, p)
+    assert (fro == ofro).all() and amb == bool(oamb) and (prog == oracle.compile(ofro, M)).all()
+    pid = session.load_program(prog)[0]
+    fro2, prog2, _ = session.code(M, N // 2, p)
+    assert session.load_program(prog2)[0] == pid and (fro2 == fro).all()
+    fro3, prog3, _ = session.code(M, N // 2, design_probability(0.0))
+    assert session.load_program(prog3)[0] != pid and (fro3 != fro).any()
+    out = io.StringIO()
+    rows = ber_sweep(session, M, systematic=True, chunk=2048, max_frames=4096, out=out)
+    by = {round(r[0], 1): r for r in rows}
+    assert by[-3.0][1] > 1e-2 and rows[-1][1] == 0.0 and -1.5 <= rows[-4][0] <= 1.0
+    assert all(len(x.split()) == 4 for x in out.getvalue().splitlines() if not x.startswith("#"))
+    rows_e = ber_sweep(session, M, systematic=False, chunk=2048, max_frames=2048, per_snr_design=True, out=io.StringIO())
+    assert rows_e[0][1] > 1e-2 and rows_e[-1][1] == 0.0
+
+
 def test_mixed_sizes_in_one_launch_set(session, oracle):
     """BASELINE config E: codes of N = 2^10 .. 2^16, each with its own design SNR (its own frozen
     set and program), resident together and decoded back to back on one stream without a host

@@ -202,3 +202,43 @@ def test_cpp_dropin_header_compiles():
     with tempfile.TemporaryDirectory() as d:
         subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"),
                         os.path.join(ROOT, "tests", "cpp", "dropin_test.cc"), "-L" + os.path.join(ROOT, "polar_amd"), "-lpolar_hip"], check=True)
+
+
+def test_product_construction_at_other_rates_and_design_points():
+    """libpolar_hip.so's PolarCodeConst0 + PolarCompiler against digests of the genuine reference at
+    K = N/4, N/2, 3N/4 and eight erasure probabilities (tests/golden/const0_variants.json), through
+    the single and the batched entry point. Cases with an exact tie at the K boundary are
+    implementation-defined in the reference (std::nth_element, polar_freezer.hh:56): there only
+    the flag is checked. Frozen sets the reference cannot compile (it asserts) must be refused."""
+    import json
+    import os
+
+    import polar_amd
+    from oracle_lib import fnv1a64
+
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "const0_variants.json")))["cases"]
+    assert len(cases) >= 100
+    c0 = polar_amd.PolarCodeConst0()
+    groups = {}
+    for c in cases:
+        M, K, p = c["M"], c["K"], float(c["p"])
+        fro = np.zeros(1 << M, np.uint8)
+        amb = c0.ambiguous(fro, M, K, p)
+        assert int(amb) == c["tie_at_boundary"], c
+        assert int((fro == 0).sum()) == K
+        if not c["tie_at_boundary"]:
+            assert "%016x" % fnv1a64(fro) == c["frozen_fnv"], c
+            prog = np.zeros(2 * (1 << M) + 1, np.uint8)
+            if c["compilable"]:
+                n = polar_amd.PolarCompiler()(prog, fro, M)
+                assert n == c["prog_len"] and "%016x" % fnv1a64(prog[:n]) == c["prog_fnv"], c
+            else:
+                with pytest.raises(polar_amd.PolarError):
+                    polar_amd.PolarCompiler()(prog, fro, M)
+        groups.setdefault((M, K), []).append(c)
+    for (M, K), cs in groups.items():  # one design-SNR list per (M, K), built in parallel
+        fro, amb = c0.batch(M, K, [float(c["p"]) for c in cs])
+        for i, c in enumerate(cs):
+            assert int(amb[i]) == c["tie_at_boundary"]
+            if not c["tie_at_boundary"]:
+                assert "%016x" % fnv1a64(fro[i]) == c["frozen_fnv"], c

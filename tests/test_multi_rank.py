@@ -112,3 +112,85 @@ def test_bench_launcher_refuses_missing_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
+
+
+class _FakeSession:
+    """Stands in for polar_amd.Session in the sweep harness tests: `simulate` reports one
+    uncorrected error per frame below -1.0 dB (per 64 frames between -1.0 and -0.5 dB), none above."""
+
+    def __init__(self):
+        self.calls = []
+
+    def code(self, M, K, p):
+        return np.zeros(1 << M, np.uint8), np.array([M, 3, 255], np.uint8), False
+
+    def simulate(self, counters, program, frozen, level, systematic, snr_db, seed, first_frame, frames):
+        self.calls.append((round(snr_db, 6), first_frame, frames))
+        err = frames if snr_db < -1.0 - 1e-9 else (frames // 64 if snr_db < -0.5 - 1e-9 else 0)
+        counters += torch.tensor([0, 0, err, 0, frames, frames * (1 << level) // 2], dtype=torch.int64)
+
+    def last_decode_ms(self):
+        return 1.0
+
+
+def test_sweep_harness_follows_the_reference_loop():
+    """testbench.cc:105-110, 125, 197-201: points from floor(design - 3) in 0.1 dB steps, the 1000-error
+    budget per point, and the stop after the run of clean points that follows the last bad one."""
+    import io
+
+    from polar_amd.sweep import ber_sweep, design_snr, snr_points
+
+    pts = list(snr_points(design_snr()))
+    assert pts[0] == -5.0 and abs(pts[1] + 4.9) < 1e-12 and pts[-1] < 4.0 + 1e-9
+    s = _FakeSession()
+    out = io.StringIO()
+    rows = ber_sweep(s, 10, chunk=256, max_frames=4096, out=out, device=torch.device("cpu"))
+    snrs = [r[0] for r in rows]
+    assert snrs[0] == -5.0
+    bad = [r for r in rows if r[5][2] > 0]
+    assert abs(bad[-1][0] + 0.6) < 1e-9              # last erroneous point
+    assert len(rows) == len(bad) + 3                  # then three clean points, then stop (count <= 3)
+    assert rows[0][4] == 1024                         # 1000-error budget: four chunks of 256 at one error per frame
+    assert rows[len(bad) - 1][4] == 4096              # few errors: the whole frame budget
+    assert all(abs(r[1] - r[5][2] / r[5][5]) < 1e-15 for r in rows)
+    text = out.getvalue().splitlines()
+    assert text[1] == "# SNR BER Mbit/s Eb/N0" and len(text[2].split()) == 4 and text[-1].startswith("# QEF at: -0.5")
+
+
+def _sweep_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import io
+
+    from polar_amd.sweep import ber_sweep
+
+    s = _FakeSession()
+    rows = ber_sweep(s, 10, chunk=256, max_frames=4096, out=io.StringIO(), device=torch.device("cpu"), dist=dist, rank=rank, world=world)
+    q.put((rank, [(r[4], r[5][2]) for r in rows], s.calls[:2]))
+    dist.destroy_process_group()
+
+
+def test_sweep_harness_two_ranks():
+    """Frames of a chunk are sharded over the ranks, the counters all-reduced between chunks and the
+    error budget evaluated on the reduced value: both ranks see the single-rank totals."""
+    import io
+
+    from polar_amd.sweep import ber_sweep
+
+    single = ber_sweep(_FakeSession(), 10, chunk=256, max_frames=4096, out=io.StringIO(), device=torch.device("cpu"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sweep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    want = [(r[4], r[5][2]) for r in single]
+    assert results[0][1] == want and results[1][1] == want
+    # rank 0 took frames [0, 128) and rank 1 [128, 256) of the first chunk of the first point
+    assert results[0][2][0][1:] == (0, 128) and results[1][2][0][1:] == (128, 128)
