@@ -118,6 +118,14 @@ int polar_hip_decode(polar_hip_handle *h, int program_id, int8_t *message, const
  * the latter waits for the device). Launches after that only enqueue. */
 int polar_hip_decode_async(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, void *stream);
 
+/* The float path of the reference: PolarDecoder<SIMD<float,W>,MAX_M>::operator() with
+ * PolarHelper<SIMD<VALUE,WIDTH>> (polar_helper.hh:62-111), selected in the bench by
+ * `typedef float code_type` (testbench.cc:49-53). codeword: N x frames float LLRs, message:
+ * K x frames float decisions (+1 / -1 / 0), same layout as the int8 call. Results equal the
+ * reference's AVX2 build bit for bit, signed zeros included; meant for BER comparisons against the
+ * int8 decoder (one frame per lane, all state in HBM), not for throughput. */
+int polar_hip_decode_f32(polar_hip_handle *h, int program_id, float *message, const float *codeword, size_t frames, int where);
+
 /* No counterpart in the reference: polar_hip_decode_async for callers that cannot allocate --
  * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc. The
  * wavefront scratch arenas come from a file-scope device array of POLAR_STATIC_SCRATCH_BYTES

@@ -530,3 +530,165 @@ void oracle_channel(int8_t *llr, const int8_t *codeword, size_t rows, size_t fra
 			llr[i * frames + f] = oracle_quant(fact * y);           /* testbench.cc:164-165 */
 		}
 }
+
+/* ---- float decoder: PolarDecoder<SIMD<float,W>,M> with PolarHelper<SIMD<VALUE,WIDTH>>
+ *      (polar_helper.hh:62-111), the instantiation the reference bench selects with
+ *      `typedef float code_type` (testbench.cc:49-53). TEST INFRASTRUCTURE ONLY.
+ *      Per lane, in the AVX2 forms of the reference (avx2.hh:514-521 vsignum: +0 for +-0,
+ *      else copysign(1, a); avx2.hh:602-610 vcopysign; vmin(a, b) = a < b ? a : b). Signed
+ *      zeros matter: prod can yield -0, and decide(-0) = -1. ---- */
+
+static float f_signum(float a) { return a == 0.0f ? 0.0f : copysignf(1.0f, a); }
+static float f_decide(float a) { return copysignf(1.0f, a); }
+static float f_min(float a, float b) { return a < b ? a : b; }
+static float f_prod(float a, float b)
+{
+	volatile float s = f_signum(a) * f_signum(b); /* vmul(vmul(sa, sb), vmin(|a|, |b|)), polar_helper.hh:98-101 */
+	return s * f_min(fabsf(a), fabsf(b));
+}
+static float f_madd(float h, float a, float b)
+{
+	volatile float p = h * a; /* vadd(vmul(a, b), c): two roundings, polar_helper.hh:102-105 */
+	return p + b;
+}
+
+static void f_trans(float *out, const float *inp, int length)
+{
+	for (int i = 0; i < length; i += 2) {
+		out[i] = inp[i] * inp[i + 1];
+		out[i + 1] = inp[i + 1];
+	}
+	for (int h = 2; h < length; h *= 2)
+		for (int i = 0; i < length; i += 2 * h)
+			for (int j = i; j < i + h; ++j)
+				out[j] = out[j] * out[j + h];
+}
+
+/* one frame; message: rows out (stride `stride` floats), codeword: N in (stride `stride`) */
+static long f_decode_frame(float *message, const float *codeword, const uint8_t *program, size_t stride, float *soft, float *hard, float *tmp)
+{
+	int top = program[0], lvl = top;
+	size_t n = (size_t)1 << top;
+	float *hrd = hard;
+	long row = 0;
+	for (size_t i = 0; i < n; ++i)
+		soft[n + i] = codeword[i * stride];
+	for (const uint8_t *pc = program + 1; *pc != 255; ++pc) {
+		int length;
+		switch (*pc) {
+		case 0: /* left, polar_decoder.hh:28-35 */
+			length = 1 << lvl;
+			for (int i = 0; i < length / 2; ++i)
+				soft[i + length / 2] = f_prod(soft[i + length], soft[i + length / 2 + length]);
+			--lvl;
+			break;
+		case 1: /* right :36-43 */
+			length = 1 << (lvl + 1);
+			for (int i = 0; i < length / 2; ++i)
+				soft[i + length / 2] = f_madd(hrd[i], soft[i + length], soft[i + length / 2 + length]);
+			hrd += 1 << lvl;
+			break;
+		case 2: /* comb :52-59 */
+			hrd -= 1 << lvl;
+			++lvl;
+			length = 1 << lvl;
+			for (int i = 0; i < length / 2; ++i)
+				hrd[i] = hrd[i] * hrd[i + length / 2];
+			break;
+		case 3: /* rate0 :68-75 */
+			for (int i = 0; i < (1 << lvl); ++i)
+				hrd[i] = 1.0f;
+			break;
+		case 4: /* rate1 :85-93 */
+			length = 1 << lvl;
+			for (int i = 0; i < length; ++i)
+				hrd[i] = f_signum(soft[i + length]);
+			f_trans(tmp, hrd, length);
+			for (int i = 0; i < length; ++i)
+				message[(size_t)(row + i) * stride] = tmp[i];
+			row += length;
+			break;
+		case 5: /* rep :94-106 */
+			length = 1 << lvl;
+			for (int h = length; h; h /= 2)
+				for (int i = 0; i < h / 2; ++i)
+					soft[i + h / 2] = soft[i + h] + soft[i + h / 2 + h];
+			{
+				float d = f_signum(soft[1]);
+				message[(size_t)row * stride] = d;
+				for (int i = 0; i < length; ++i)
+					hrd[i] = d;
+			}
+			++row;
+			break;
+		case 6: /* spc :107-127 */
+			length = 1 << lvl;
+			{
+				for (int i = 0; i < length; ++i)
+					hrd[i] = f_decide(soft[i + length]);
+				float parity = hrd[0];
+				for (int i = 1; i < length; ++i)
+					parity = parity * hrd[i];
+				for (int i = 0; i < length; ++i)
+					soft[i] = fabsf(soft[i + length]);
+				float weak = soft[0];
+				for (int i = 1; i < length; ++i)
+					weak = f_min(weak, soft[i]);
+				for (int i = 0; i < length; ++i)
+					hrd[i] = weak == soft[i] ? hrd[i] * parity : hrd[i];
+				f_trans(soft, hrd, length);
+				for (int i = 0; i < length - 1; ++i)
+					message[(size_t)(row + i) * stride] = soft[i + 1];
+			}
+			row += length - 1;
+			break;
+		case 7: /* rate0_right :44-51 */
+			length = 1 << lvl;
+			for (int i = 0; i < length / 2; ++i)
+				soft[i + length / 2] = soft[i + length] + soft[i + length / 2 + length];
+			--lvl;
+			hrd += 1 << lvl;
+			break;
+		case 8: /* rate0_comb :60-67 */
+			hrd -= 1 << lvl;
+			++lvl;
+			length = 1 << lvl;
+			for (int i = 0; i < length / 2; ++i)
+				hrd[i] = hrd[i + length / 2];
+			break;
+		case 9: /* rate1_comb :76-84 */
+			++lvl;
+			length = 1 << (lvl - 1);
+			for (int i = 0; i < length; ++i) {
+				float r = f_signum(f_madd(hrd[i], soft[i + 2 * length], soft[i + 3 * length]));
+				hrd[i + length] = r;
+				hrd[i] = hrd[i] * r;
+			}
+			f_trans(tmp, hrd + length, length);
+			for (int i = 0; i < length; ++i)
+				message[(size_t)(row + i) * stride] = tmp[i];
+			row += length;
+			break;
+		default:
+			return -1;
+		}
+	}
+	return lvl == top ? row : -1;
+}
+
+/* message: rows x frames out, codeword: N x frames in, [elem][frame] floats. Returns rows. */
+long oracle_decode_f32(float *message, const float *codeword, const uint8_t *program, size_t frames)
+{
+	int top = program[0];
+	if (top < 1 || top > 24)
+		return -1;
+	size_t n = (size_t)1 << top;
+	float *soft = malloc(2 * n * sizeof(float)), *hard = malloc(n * sizeof(float)), *tmp = malloc(n * sizeof(float));
+	long rows = 0;
+	for (size_t f = 0; f < frames && rows >= 0; ++f)
+		rows = f_decode_frame(message + f, codeword + f, program, frames, soft, hard, tmp);
+	free(soft);
+	free(hard);
+	free(tmp);
+	return rows;
+}

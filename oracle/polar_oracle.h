@@ -84,4 +84,7 @@ double oracle_decode_time(const int8_t *codeword, const uint8_t *program, size_t
 }
 #endif
 
+/* float decoder, PolarDecoder<SIMD<float,W>,M> semantics (polar_helper.hh:62-111), [elem][frame] floats */
+long oracle_decode_f32(float *message, const float *codeword, const uint8_t *program, size_t frames);
+
 #endif

@@ -88,6 +88,17 @@ static void *xaligned(size_t bytes)
 	return p;
 }
 
+static const int REF_WF = REF_W / 4;
+typedef SIMD<float, REF_WF> simd_float;
+template <int M> static void dec_run_f32(float *message, const float *codeword, const uint8_t *program)
+{
+	typedef PolarDecoder<simd_float, M> D;
+	D *d = (D *)xaligned(sizeof(D));
+	(*d)(reinterpret_cast<simd_float *>(message), reinterpret_cast<const simd_float *>(codeword), program);
+	free(d);
+}
+
+
 extern "C" {
 
 int ref_simd_width() { return REF_W; }
@@ -236,6 +247,38 @@ int ref_op(int which, int a, int b, int c)
 int ref_quant(double x)
 {
 	return PolarHelper<int8_t>::quant(x);
+}
+
+/*
+ * float decoder: PolarDecoder<SIMD<float, 8>, M> (testbench.cc:49-53 with `typedef float code_type`,
+ * AVX2 width 32 / sizeof(float)). message: K x frames, codeword: N x frames floats, [elem][frame].
+ */
+int ref_decode_f32(float *message, const float *codeword, const uint8_t *program, int K, long frames)
+{
+	int level = program[0];
+	if (level > 16)
+		return -1;
+	long N = 1L << level;
+	float *cw = (float *)xaligned(sizeof(float) * (size_t)N * REF_WF);
+	float *ms = (float *)xaligned(sizeof(float) * (size_t)N * REF_WF);
+	for (long f0 = 0; f0 < frames; f0 += REF_WF) {
+		long w = std::min<long>(REF_WF, frames - f0);
+		for (long i = 0; i < N; ++i)
+			for (long k = 0; k < REF_WF; ++k)
+				cw[i * REF_WF + k] = k < w ? codeword[i * frames + f0 + k] : 0.f;
+		if (level <= 8)
+			dec_run_f32<8>(ms, cw, program);
+		else if (level <= 12)
+			dec_run_f32<12>(ms, cw, program);
+		else
+			dec_run_f32<16>(ms, cw, program);
+		for (long i = 0; i < K; ++i)
+			for (long k = 0; k < w; ++k)
+				message[i * frames + f0 + k] = ms[i * REF_WF + k];
+	}
+	free(cw);
+	free(ms);
+	return 0;
 }
 
 }

@@ -27,6 +27,7 @@ SYMBOLS = {
     "polar_hip_code": ([_vp, _i, _i, _ld, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
     "polar_hip_decode": ([_vp, _i, _vp, _vp, _sz, _i], _i),
     "polar_hip_decode_async": ([_vp, _i, _vp, _vp, _sz, _vp], _i),
+    "polar_hip_decode_f32": ([_vp, _i, _vp, _vp, _sz, _i], _i),
     "polar_hip_decode_static": ([_vp, _i, _vp, _vp, _sz, _vp], _i),
     "polar_hip_encode": ([_vp, _i, _vp, _vp, _vp, _i, _sz, _i], _i),
     "polar_hip_systematic_extract": ([_vp, _vp, _vp, _i, _sz, _i], _i),

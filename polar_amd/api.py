@@ -227,6 +227,10 @@ def _session(session):
     return _default_session
 
 
+def _is_f32(a):
+    return str(a.dtype) in ("float32", "torch.float32")
+
+
 def _frames(a):
     return int(a.shape[1]) if a.ndim == 2 else 1
 
@@ -246,6 +250,11 @@ class PolarDecoder:
         self.session._order(codeword)
         mp, mw = _ptr(message)
         cp, cw = _ptr(codeword)
+        if _is_f32(codeword) or _is_f32(message):  # TYPE = float lanes (testbench.cc:49-53): the reference's float helper
+            if not (_is_f32(codeword) and _is_f32(message)):
+                raise ValueError("float decoding needs float32 codeword and message buffers")
+            _check(lib.polar_hip_decode_f32(self.session._h, pid, mp, cp, frames, _where(mw, cw)), "PolarDecoder(float)")
+            return
         _check(lib.polar_hip_decode(self.session._h, pid, mp, cp, frames, _where(mw, cw)), "PolarDecoder")
 
     def launch(self, message, codeword, program, stream):

@@ -1,0 +1,74 @@
+// decode_kernel.hpp -- the decode kernel template and the table entry of one compiled variant.
+// The variants are instantiated in several translation units (variants.hip, one group each)
+// so that they compile in parallel; polar_hip.hip collects the groups.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "sc_core.hpp"
+
+using namespace polar;
+
+struct DecodeArgs {
+	const DevOp *prog;
+	const uint8_t *cw;
+	uint8_t *msg;
+	u32 *scratch;          // per-block arenas, block_dwords each
+	size_t block_dwords;
+	size_t stride;         // bytes per row of cw and msg: a multiple of 4, groups * 4Q <= stride
+	u32 groups;
+	int top;
+	unsigned long long *prof; // diagnostic build (POLAR_PROFILE) only
+};
+
+// Persistent wavefronts: block b walks the groups b, b + gridDim, ... Blocks are dealt to
+// the 8 XCDs round-robin, so within one sweep the blocks that share an XCD (equal b % 8) take
+// neighbouring groups: those groups share the 128-byte lines of every input row.
+// The occupancy hint stays at 4 waves per SIMD for every variant. The 20 KiB-of-LDS variants
+// cannot reach it (8 workgroups per CU) and the compiler then uses ~200 VGPRs anyway, but asking
+// for 2 instead made it schedule the chain loops worse: 15 % slower, measured A/B on one box.
+template <int Q, int RL>
+__global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
+{
+	typedef Group<Q, RL> G;
+	__shared__ __attribute__((aligned(16))) u32 lds[G::LDS_DWORDS];
+	const u32 nb = gridDim.x, b = blockIdx.x;
+	const u32 slot = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+	u32 *arena = a.scratch ? a.scratch + (size_t)b * a.block_dwords : nullptr;
+	const size_t plane = ((size_t)Q << a.top) / 8;
+	G g;
+	g.sl = (lds_u32 *)lds;
+	g.hls = g.sl + G::LDS_SOFT;
+	g.hlz = g.hls + G::LDS_PLANE;
+	g.sg = arena;
+	g.hgs = arena ? arena + ((size_t)Q << a.top) : nullptr;
+	g.hgz = arena ? g.hgs + plane : nullptr;
+	g.top = a.top;
+#ifdef POLAR_PROFILE
+	g.prof = a.prof;
+#endif
+	for (u32 base = 0; base < a.groups; base += nb) {
+		u32 grp = base + slot;
+		if (grp >= a.groups)
+			continue;
+		size_t g0 = (size_t)grp * (4 * Q);
+		g.in = InVec<Q>{a.cw + g0, a.stride};
+		g.out = OutRows<Q>{a.msg + g0, a.stride};
+		g.run((prog_ptr)a.prog);
+	}
+}
+
+typedef void (*decode_kernel_t)(DecodeArgs);
+
+struct KernelVariant {
+	int q, rl;
+	decode_kernel_t fn;
+	size_t lds_bytes;
+	int chain_depth;
+};
+
+enum { VARIANT_GROUPS = 8 };
+// the variants compiled into group g (variants.hip with -DVARIANT_GROUP=g)
+#define DECLARE_GROUP(g) const KernelVariant *polar_variant_group_##g(int *count);
+DECLARE_GROUP(0) DECLARE_GROUP(1) DECLARE_GROUP(2) DECLARE_GROUP(3) DECLARE_GROUP(4) DECLARE_GROUP(5) DECLARE_GROUP(6) DECLARE_GROUP(7)
+#undef DECLARE_GROUP

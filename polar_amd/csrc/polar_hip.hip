@@ -21,7 +21,7 @@
 #include "construct.hpp"
 #include "program.hpp"
 #include "channel.hpp"
-#include "sc_core.hpp"
+#include "decode_kernel.hpp"
 
 using namespace polar;
 
@@ -44,80 +44,30 @@ static int fail(int code, const std::string &msg)
 // decoder kernel
 // ---------------------------------------------------------------------------------------
 
-struct DecodeArgs {
-	const DevOp *prog;
-	const uint8_t *cw;
-	uint8_t *msg;
-	u32 *scratch;          // per-block arenas, block_dwords each
-	size_t block_dwords;
-	size_t stride;         // bytes per row of cw and msg: a multiple of 4, groups * 4Q <= stride
-	u32 groups;
-	int top;
-	unsigned long long *prof; // diagnostic build (POLAR_PROFILE) only
-};
-
-// Persistent wavefronts: block b walks the groups b, b + gridDim, ... Blocks are dealt to
-// the 8 XCDs round-robin, so within one sweep the blocks that share an XCD (equal b % 8) take
-// neighbouring groups: those groups share the 128-byte lines of every input row.
-// The occupancy hint stays at 4 waves per SIMD for every variant. The 20 KiB-of-LDS variants
-// cannot reach it (8 workgroups per CU) and the compiler then uses ~200 VGPRs anyway, but asking
-// for 2 instead made it schedule the chain loops worse: 15 % slower, measured A/B on one box.
-template <int Q, int RL>
-__global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
-{
-	typedef Group<Q, RL> G;
-	__shared__ __attribute__((aligned(16))) u32 lds[G::LDS_DWORDS];
-	const u32 nb = gridDim.x, b = blockIdx.x;
-	const u32 slot = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
-	u32 *arena = a.scratch ? a.scratch + (size_t)b * a.block_dwords : nullptr;
-	const size_t plane = ((size_t)Q << a.top) / 8;
-	G g;
-	g.sl = (lds_u32 *)lds;
-	g.hls = g.sl + G::LDS_SOFT;
-	g.hlz = g.hls + G::LDS_PLANE;
-	g.sg = arena;
-	g.hgs = arena ? arena + ((size_t)Q << a.top) : nullptr;
-	g.hgz = arena ? g.hgs + plane : nullptr;
-	g.top = a.top;
-#ifdef POLAR_PROFILE
-	g.prof = a.prof;
-#endif
-	for (u32 base = 0; base < a.groups; base += nb) {
-		u32 grp = base + slot;
-		if (grp >= a.groups)
-			continue;
-		size_t g0 = (size_t)grp * (4 * Q);
-		g.in = InVec<Q>{a.cw + g0, a.stride};
-		g.out = OutRows<Q>{a.msg + g0, a.stride};
-		g.run((prog_ptr)a.prog);
+// all compiled decode-kernel variants (variants.hip, one group per translation unit)
+struct VariantTable {
+	std::vector<KernelVariant> v;
+	VariantTable()
+	{
+		typedef const KernelVariant *(*group_fn)(int *);
+		static const group_fn groups[VARIANT_GROUPS] = {polar_variant_group_0, polar_variant_group_1, polar_variant_group_2, polar_variant_group_3,
+			polar_variant_group_4, polar_variant_group_5, polar_variant_group_6, polar_variant_group_7};
+		for (group_fn g : groups) {
+			int n = 0;
+			const KernelVariant *t = g(&n);
+			v.insert(v.end(), t, t + n);
+		}
 	}
+};
+static const std::vector<KernelVariant> &variants()
+{
+	static const VariantTable t;
+	return t.v;
 }
-
-typedef void (*decode_kernel_t)(DecodeArgs);
-
-struct KernelVariant {
-	int q, rl;
-	decode_kernel_t fn;
-	size_t lds_bytes;
-	int chain_depth;
-};
-
-#define VARIANT(q, rl) {q, rl, sc_decode_kernel<q, rl>, sizeof(u32) * (size_t)Group<q, rl>::LDS_DWORDS, Group<q, rl>::CHAIN_DEPTH}
-static const KernelVariant g_variants[] = {
-	// 256 frames per wavefront: every node keeps all 64 lanes busy
-	VARIANT(64, 4), VARIANT(64, 5), VARIANT(64, 6), VARIANT(32, 5), VARIANT(32, 6), VARIANT(32, 7),
-	// ~10 KB of LDS per wavefront (15 wavefronts per CU)
-	VARIANT(16, 6), VARIANT(8, 7),
-	// ~20 KB (7 per CU)
-	VARIANT(1, 11), VARIANT(2, 10), VARIANT(4, 9), VARIANT(8, 8), VARIANT(16, 7),
-	// ~40 KB (3 per CU)
-	VARIANT(4, 10), VARIANT(4, 8),
-};
-#undef VARIANT
 
 static const KernelVariant *find_variant(int q, int rl)
 {
-	for (const KernelVariant &v : g_variants)
+	for (const KernelVariant &v : variants())
 		if (v.q == q && v.rl == rl)
 			return &v;
 	return nullptr;
@@ -131,6 +81,136 @@ enum : size_t { STATIC_SCRATCH_BYTES = (size_t)POLAR_STATIC_SCRATCH_BYTES };
 static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
 enum { MAX_DEVICES = 64, STATIC_Q = 8, STATIC_RL = 8 }; // the kernel shape of the static entry point: 32 frames per wavefront
 static void *g_static_scratch[MAX_DEVICES];
+
+// ---------------------------------------------------------------------------------------
+// float decoder: PolarDecoder<SIMD<float,W>,M> with PolarHelper<SIMD<VALUE,WIDTH>>
+// (polar_helper.hh:62-111), the path the reference bench takes with `typedef float code_type`
+// (testbench.cc:49-53) -- for BER comparisons against the int8 decoder, not for speed.
+// One lane = one frame, exactly the reference's per-lane arithmetic in its AVX2 forms (vsignum:
+// +0 for +-0 else copysign(1, a), avx2.hh:514-521; vcopysign :602-610; vmin(a, b) = a < b ? a : b),
+// signed zeros included. soft[2N] / hard[N] (polar_decoder.hh:128-129) live in a per-wave arena,
+// element-major / lane-minor so that every access of the wave is one 256-byte row.
+// ---------------------------------------------------------------------------------------
+struct FloatArgs {
+	const uint8_t *prog; // the reference byte-code itself
+	const float *cw;     // [N][frames]
+	float *msg;          // [rows][frames]
+	float *arena;        // per workgroup: 3N x 64 floats
+	size_t frames;
+	u32 groups;
+	int top;
+};
+
+__device__ __forceinline__ float f_signum(float a) { return a == 0.0f ? 0.0f : copysignf(1.0f, a); }
+__device__ __forceinline__ float f_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float f_prod(float a, float b) { return (f_signum(a) * f_signum(b)) * f_min(fabsf(a), fabsf(b)); }
+
+// trans (polar_decoder.hh:15-27) of `length` symbols: out / inp are lane columns with the given strides
+__device__ __forceinline__ void f_trans(float *out, size_t os, const float *inp, size_t is, int length, bool active)
+{
+	if (!active)
+		return;
+	for (int i = 0; i < length; i += 2) {
+		float b = inp[(size_t)(i + 1) * is];
+		out[(size_t)i * os] = inp[(size_t)i * is] * b;
+		out[(size_t)(i + 1) * os] = b;
+	}
+	for (int h = 2; h < length; h *= 2)
+		for (int i = 0; i < length; i += 2 * h)
+			for (int j = i; j < i + h; ++j)
+				out[(size_t)j * os] = out[(size_t)j * os] * out[(size_t)(j + h) * os];
+}
+
+__global__ void __launch_bounds__(64) sc_decode_f32_kernel(FloatArgs a)
+{
+	const size_t n = (size_t)1 << a.top;
+	float *soft = a.arena + (size_t)blockIdx.x * 3 * n * 64 + threadIdx.x; // soft[i] at soft + 64 * i
+	float *hard0 = soft + 2 * n * 64;
+	for (u32 grp = blockIdx.x; grp < a.groups; grp += gridDim.x) {
+		const size_t f = (size_t)grp * 64 + threadIdx.x;
+		const bool active = f < a.frames;
+		const float *cw = a.cw + (active ? f : 0);
+		float *msg = a.msg + (active ? f : 0);
+		for (size_t i = 0; i < n; ++i) // polar_decoder.hh:136-137
+			soft[(n + i) * 64] = cw[i * a.frames];
+		float *hrd = hard0;
+		int lvl = a.top;
+		size_t row = 0;
+		for (const uint8_t *pc = a.prog + 1; *pc != 255; ++pc) {
+			const u32 op = *pc;
+			if (op == OP_LEFT || op == OP_RATE0_RIGHT) {
+				size_t len = (size_t)1 << lvl, h = len / 2;
+				for (size_t i = 0; i < h; ++i) {
+					float x = soft[(len + i) * 64], y = soft[(len + h + i) * 64];
+					soft[(h + i) * 64] = op == OP_LEFT ? f_prod(x, y) : x + y;
+				}
+				--lvl;
+				if (op == OP_RATE0_RIGHT)
+					hrd += ((size_t)64 << lvl);
+			} else if (op == OP_RIGHT) {
+				size_t len = (size_t)2 << lvl, h = len / 2;
+				for (size_t i = 0; i < h; ++i)
+					soft[(h + i) * 64] = hrd[i * 64] * soft[(len + i) * 64] + soft[(len + h + i) * 64];
+				hrd += ((size_t)64 << lvl);
+			} else if (op == OP_COMB || op == OP_RATE0_COMB) {
+				hrd -= ((size_t)64 << lvl);
+				++lvl;
+				size_t h = (size_t)1 << (lvl - 1);
+				for (size_t i = 0; i < h; ++i)
+					hrd[i * 64] = op == OP_COMB ? hrd[i * 64] * hrd[(i + h) * 64] : hrd[(i + h) * 64];
+			} else if (op == OP_RATE0) {
+				for (size_t i = 0; i < ((size_t)1 << lvl); ++i)
+					hrd[i * 64] = 1.0f;
+			} else if (op == OP_RATE1) {
+				size_t len = (size_t)1 << lvl;
+				for (size_t i = 0; i < len; ++i)
+					hrd[i * 64] = f_signum(soft[(len + i) * 64]);
+				f_trans(msg + row * a.frames, a.frames, hrd, 64, (int)len, active);
+				row += len;
+			} else if (op == OP_REP) {
+				size_t len = (size_t)1 << lvl;
+				for (size_t h = len; h; h /= 2)
+					for (size_t i = 0; i < h / 2; ++i)
+						soft[(h / 2 + i) * 64] = soft[(h + i) * 64] + soft[(h + h / 2 + i) * 64];
+				float d = f_signum(soft[64]);
+				if (active)
+					msg[row * a.frames] = d;
+				for (size_t i = 0; i < len; ++i)
+					hrd[i * 64] = d;
+				++row;
+			} else if (op == OP_SPC) {
+				size_t len = (size_t)1 << lvl;
+				float parity = 1.0f, weak = 0.0f;
+				for (size_t i = 0; i < len; ++i) {
+					float x = soft[(len + i) * 64], d = copysignf(1.0f, x), m = fabsf(x);
+					hrd[i * 64] = d;
+					soft[i * 64] = m;
+					parity = i ? parity * d : d;
+					weak = i ? f_min(weak, m) : m;
+				}
+				for (size_t i = 0; i < len; ++i)
+					if (weak == soft[i * 64])
+						hrd[i * 64] = hrd[i * 64] * parity;
+				f_trans(soft, 64, hrd, 64, (int)len, true);
+				if (active)
+					for (size_t i = 0; i + 1 < len; ++i)
+						msg[(row + i) * a.frames] = soft[(i + 1) * 64];
+				row += len - 1;
+			} else if (op == OP_RATE1_COMB) {
+				++lvl;
+				size_t h = (size_t)1 << (lvl - 1);
+				for (size_t i = 0; i < h; ++i) {
+					float l = hrd[i * 64];
+					float r = f_signum(l * soft[(2 * h + i) * 64] + soft[(3 * h + i) * 64]);
+					hrd[(i + h) * 64] = r;
+					hrd[i * 64] = l * r;
+				}
+				f_trans(msg + row * a.frames, a.frames, hrd + h * 64, 64, (int)h, active);
+				row += h;
+			}
+		}
+	}
+}
 
 // ---------------------------------------------------------------------------------------
 // encoder kernels
@@ -478,6 +558,7 @@ struct LoadedProgram {
 	HostProgram host;                // unfused translation: level, rows, validation
 	std::vector<uint8_t> bytes;      // the reference byte-code as loaded
 	std::map<int, DevOp *> dev;      // device instruction stream per frame-quads-per-wave (fusion depends on it)
+	uint8_t *dev_bytes = nullptr;    // the byte-code itself on the device (float decoder)
 };
 
 struct polar_hip_handle {
@@ -654,9 +735,12 @@ extern "C" void polar_hip_destroy(polar_hip_handle *h)
 	(void)hipStreamSynchronize(h->stream);
 	if (h->stream != h->own_stream)
 		(void)hipStreamSynchronize(h->own_stream);
-	for (auto &p : h->programs)
+	for (auto &p : h->programs) {
 		for (auto &d : p.dev)
 			(void)hipFree(d.second);
+		if (p.dev_bytes)
+			(void)hipFree(p.dev_bytes);
+	}
 	h->scratch.release();
 	h->stage_in.release();
 	h->stage_out.release();
@@ -681,7 +765,7 @@ extern "C" int polar_hip_configure(polar_hip_handle *h, int frames_per_wave, int
 		return fail(POLAR_E_ARG, "polar_hip_configure: null handle");
 	if (frames_per_wave || lds_level) {
 		bool found = false;
-		for (const KernelVariant &v : g_variants)
+		for (const KernelVariant &v : variants())
 			found |= 4 * v.q == frames_per_wave && v.rl == lds_level;
 		if (!found)
 			return fail(POLAR_E_ARG, "polar_hip_configure: no kernel built for this (frames_per_wave, lds_level)");
@@ -1060,6 +1144,66 @@ extern "C" int polar_hip_synchronize(polar_hip_handle *h)
 	int rc = use_device(h);
 	if (rc)
 		return rc;
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	return POLAR_OK;
+}
+
+// ---- float decoder ----
+
+extern "C" int polar_hip_decode_f32(polar_hip_handle *h, int program_id, float *message, const float *codeword, size_t frames, int where)
+{
+	int rc = check_decode_args(h, program_id, message, codeword, frames);
+	if (rc)
+		return rc;
+	if (where != POLAR_HOST && where != POLAR_DEVICE)
+		return fail(POLAR_E_ARG, "polar_hip_decode_f32: bad `where`");
+	if ((rc = use_device(h)))
+		return rc;
+	if (!frames)
+		return POLAR_OK;
+	LoadedProgram &lp = h->programs[program_id];
+	const size_t n = (size_t)1 << lp.host.top, rows = lp.host.rows;
+	const size_t groups = (frames + 63) / 64, per_wave = 3 * n * 64 * sizeof(float);
+	if (groups > 0x7FFFFFFFu)
+		return fail(POLAR_E_ARG, "too many frames for one call");
+	if (!lp.dev_bytes) { // the float kernel interprets the reference byte-code as it is
+		HIP_TRY(hipMalloc((void **)&lp.dev_bytes, lp.bytes.size()));
+		HIP_TRY(hipMemcpy(lp.dev_bytes, lp.bytes.data(), lp.bytes.size(), hipMemcpyHostToDevice));
+	}
+	ScratchBudget budget{h};
+	size_t blocks = (size_t)8 * h->cus < groups ? (size_t)8 * h->cus : groups;
+	if (!budget.fits(blocks * per_wave)) {
+		blocks = budget.limit() / per_wave;
+		if (blocks < 1)
+			return fail(POLAR_E_NOMEM, "not enough device memory for one wavefront's float arena");
+	}
+	if ((rc = h->scratch.reserve(blocks * per_wave)))
+		return rc;
+	const float *cw = codeword;
+	float *msg = message;
+	if (where == POLAR_HOST) {
+		if ((rc = h->stage_in.reserve(n * frames * sizeof(float))) || (rc = h->stage_out.reserve((rows ? rows : 1) * frames * sizeof(float))))
+			return rc;
+		HIP_TRY(hipMemcpyAsync(h->stage_in.p, codeword, n * frames * sizeof(float), hipMemcpyHostToDevice, h->stream));
+		cw = (const float *)h->stage_in.p;
+		msg = (float *)h->stage_out.p;
+	}
+	FloatArgs a;
+	a.prog = lp.dev_bytes;
+	a.cw = cw;
+	a.msg = msg;
+	a.arena = (float *)h->scratch.p;
+	a.frames = frames;
+	a.groups = (u32)groups;
+	a.top = lp.host.top;
+	h->timed = false;
+	HIP_TRY(hipEventRecord(h->ev0, h->stream));
+	hipLaunchKernelGGL(sc_decode_f32_kernel, dim3((unsigned)blocks), dim3(64), 0, h->stream, a);
+	HIP_TRY(hipGetLastError());
+	HIP_TRY(hipEventRecord(h->ev1, h->stream));
+	h->timed = true;
+	if (where == POLAR_HOST && rows)
+		HIP_TRY(hipMemcpyAsync(message, msg, rows * frames * sizeof(float), hipMemcpyDeviceToHost, h->stream));
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	return POLAR_OK;
 }

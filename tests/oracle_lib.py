@@ -54,6 +54,7 @@ class Oracle:
         L.oracle_decode.argtypes, L.oracle_decode.restype = [_vp, _vp, _vp, _sz], _l
         L.oracle_systematic_extract.argtypes, L.oracle_systematic_extract.restype = [_vp, _vp, _i, _sz], None
         L.oracle_count.argtypes, L.oracle_count.restype = [_vp, _vp, _vp, _sz, _vp, _vp, _sz], None
+        L.oracle_decode_f32.argtypes, L.oracle_decode_f32.restype = [_vp, _vp, _vp, _sz], _l
         L.oracle_decode_time.argtypes, L.oracle_decode_time.restype = [_vp, _vp, _sz, _i], ctypes.c_double
 
     def const0(self, level, K, p=None):
@@ -92,6 +93,19 @@ class Oracle:
         assert codeword.shape[0] == n
         msg = np.zeros((n, frames), np.int8)
         rows = self.L.oracle_decode(_ptr(msg), _ptr(codeword), _ptr(program), frames)
+        if rows < 0:
+            raise ValueError("malformed program")
+        return msg[:rows].copy()
+
+    def decode_f32(self, codeword, program):
+        """PolarDecoder<SIMD<float,W>,M> (the reference's float path): float32 [N][frames] -> [rows][frames]."""
+        program = _c(program, np.uint8)
+        codeword = _c(codeword, np.float32)
+        n = 1 << int(program[0])
+        frames = codeword.shape[1]
+        assert codeword.shape[0] == n
+        msg = np.zeros((n, frames), np.float32)
+        rows = self.L.oracle_decode_f32(_ptr(msg), _ptr(codeword), _ptr(program), frames)
         if rows < 0:
             raise ValueError("malformed program")
         return msg[:rows].copy()
@@ -147,6 +161,8 @@ class Ref:
         L.ref_encode.argtypes, L.ref_encode.restype = [_vp, _vp, _vp, _i, _i, _l, _i], None
         L.ref_decode.argtypes, L.ref_decode.restype = [_vp, _vp, _vp, _i, _l], None
         L.ref_decode_time.argtypes, L.ref_decode_time.restype = [_vp, _vp, _i], ctypes.c_double
+        if hasattr(L, "ref_decode_f32"):
+            L.ref_decode_f32.argtypes, L.ref_decode_f32.restype = [_vp, _vp, _vp, _i, _l], _i
         L.ref_op.argtypes, L.ref_op.restype = [_i, _i, _i, _i], _i
         L.ref_quant.argtypes, L.ref_quant.restype = [ctypes.c_double], _i
         self.width = L.ref_simd_width()
@@ -184,6 +200,13 @@ class Ref:
         frames = codeword.shape[1]
         msg = np.zeros((K, frames), np.int8)
         self.L.ref_decode(_ptr(msg), _ptr(codeword), _ptr(program), K, frames)
+        return msg
+
+    def decode_f32(self, codeword, program, K):
+        program = _c(program, np.uint8)
+        codeword = _c(codeword, np.float32)
+        msg = np.zeros((K, codeword.shape[1]), np.float32)
+        assert self.L.ref_decode_f32(_ptr(msg), _ptr(codeword), _ptr(program), K, codeword.shape[1]) == 0
         return msg
 
     def decode_time(self, codeword_bundle, program, reps):

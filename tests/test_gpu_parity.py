@@ -440,6 +440,43 @@ def test_simulate_matches_the_step_by_step_chain(session, oracle):
         assert d.cpu().numpy().tolist() == got.tolist()
 
 
+def test_float_decoder_vs_oracle(session, oracle):
+    """polar_hip_decode_f32 against the oracle's restatement of the reference's float
+    helper (itself pinned bit for bit to PolarDecoder<SIMD<float,8>,M>, tests/test_oracle_vs_ref.py).
+    Bit-exact, signed zeros included (compared as raw bytes): the float path uses exact products
+    with +-1 / 0 and IEEE additions only, so no tolerance is needed."""
+    import polar_amd
+
+    dec = polar_amd.PolarDecoder(session)
+    for M, frames in ((3, 5), (6, 64), (8, 100), (10, 130), (12, 64), (14, 70)):
+        N = 1 << M
+        for code in ("const0", "freezer"):
+            fro = _code(oracle, M, code)
+            K = int((fro == 0).sum())
+            prog = oracle.compile(fro, M)
+            cw = oracle.encode(pm1_message(M, K, frames), fro, M, 0)
+            for fam in ("awgn-1", "uniform", "small"):
+                llr = family_llr(fam, 7 * M + 2, cw).astype(np.float32)
+                exp = oracle.decode_f32(llr, prog)
+                got = np.full((K, frames), 9.0, np.float32)
+                dec(got, llr, prog)
+                assert got.tobytes() == exp.tobytes(), (M, code, fam)
+            frac = ((rand_bytes(M, (N, frames)).astype(np.float32) - 127.5) / 16.0 * cw).astype(np.float32)
+            d_in = torch.from_numpy(frac).cuda()
+            d_out = torch.zeros((K, frames), dtype=torch.float32, device="cuda")
+            dec(d_out, d_in, prog)
+            assert d_out.cpu().numpy().tobytes() == oracle.decode_f32(frac, prog).tobytes(), (M, code, "fractional")
+    # above the waterfall the float and the int8 decoder both return the transmitted message
+    M, frames = 11, 64
+    fro = _code(oracle, M)
+    prog = oracle.compile(fro, M)
+    msg = pm1_message(4, 1 << (M - 1), frames)
+    llr = family_llr("awgn+1", 77, oracle.encode(msg, fro, M, 0))
+    f = np.zeros((1 << (M - 1), frames), np.float32)
+    dec(f, llr.astype(np.float32), prog)
+    assert (f == msg).all() and (_decode(session, llr, prog, 1 << (M - 1)) == msg).all()
+
+
 def test_code_cache_and_sweep_harness(session, oracle):
     """the handle's (level, K, p) cache returns the reference's construction and one
     resident program per key; the sweep harness on top of polar_hip_simulate prints the reference's

@@ -78,3 +78,27 @@ def test_level20(oracle, ref):
     assert p.tolist() == ref.compile(f1, M).tolist() and len(p) == 114903
     llr = np.random.default_rng(1).integers(-128, 128, (N, 3)).astype(np.int8)
     assert (oracle.decode(llr, p) == ref.decode(llr, p, N // 2)).all()
+
+
+def test_float_decoder_restatement(oracle, ref):
+    """the float path (PolarHelper<SIMD<float,W>>, polar_helper.hh:62-111) restated per
+    lane against the reference's own SIMD<float, 8> decoder, bit for bit including the sign of
+    zeros: integer-valued LLRs (the quantised channel output, zeros included), fractional LLRs
+    and inputs with many exact zeros."""
+    import numpy as np
+
+    from inputs import family_llr, pm1_message, rand_bytes
+
+    for M in (3, 5, 8, 10, 12, 13):
+        N = 1 << M
+        for code in ("const0", "freezer"):
+            fro = oracle.const0(M, N // 2)[0] if code == "const0" else oracle.freezer(M, 0.5, 0.5)[0]
+            K = int((fro == 0).sum())
+            prog = oracle.compile(fro, M)
+            cw = oracle.encode(pm1_message(M, K, 19), fro, M, 0)
+            for fam in ("awgn-1", "uniform", "small"):
+                llr = family_llr(fam, 5 * M + 1, cw).astype(np.float32)
+                got, exp = oracle.decode_f32(llr, prog), ref.decode_f32(llr, prog, K)
+                assert got.tobytes() == exp.tobytes(), (M, code, fam)
+            frac = (rand_bytes(M, (N, 19)).astype(np.float32) - 127.5) / 16.0 * cw
+            assert oracle.decode_f32(frac, prog).tobytes() == ref.decode_f32(frac, prog, K).tobytes(), (M, code, "fractional")
