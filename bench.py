@@ -54,7 +54,7 @@ CONFIGS = {
     # name: (M, systematic, default frames per GPU)
     "A": (10, 0, 1 << 22),
     "B": (16, 1, 1 << 20),
-    "D": (20, 1, 1 << 15),
+    "D": (20, 1, 1 << 16),
 }
 
 
@@ -241,12 +241,13 @@ def cpu_baseline(llr_sample, prog, K, seconds):
 def load_profile_counters(frames, args):
     """HBM bytes and VALU / LDS utilisation of the decode kernel from the committed rocprofv3
     PMC passes of this same command (tools/prof_bench.sh -> profiles/hbm_traffic.json)."""
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if not os.path.exists(tpath):
-        return None
-    t = json.load(open(tpath))
-    if t.get("frames") == frames and t.get("fpw") == args.fpw and t.get("lds_level") == args.lds_level and t.get("config", "B") == args.config:
-        return t
+    for name in ("hbm_traffic.json", "hbm_traffic_%s.json" % args.config):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(tpath):
+            continue
+        t = json.load(open(tpath))
+        if t.get("frames") == frames and t.get("fpw") == args.fpw and t.get("lds_level") == args.lds_level and t.get("config", "B") == args.config and "bytes_per_launch" in t:
+            return t
     return None
 
 

@@ -116,14 +116,17 @@ public:
 
 // The reference object carries soft[2N] / hard[N] (polar_decoder.hh:128-129) and is allocated
 // by the caller; here the scratch lives on the device behind the thread's context, and the
-// last program is kept resident so repeated calls (testbench.cc:171) do not re-upload it.
+// programs stay resident (a few digests are remembered here, and polar_hip_load_program returns
+// the id of a program it already holds), so repeated calls (testbench.cc:171) and callers that
+// alternate between codes neither re-upload nor grow the handle.
 template <int W, int MAX_M>
 class PolarDecoder<GPU<int8_t, W>, MAX_M>
 {
 	typedef GPU<int8_t, W> TYPE;
-	const uint8_t *last_program = nullptr;
-	uint64_t last_digest = 0;
-	int program_id = -1;
+	enum { REMEMBERED = 8 };
+	uint64_t digests[REMEMBERED] = {};
+	int ids[REMEMBERED] = {-1, -1, -1, -1, -1, -1, -1, -1};
+	int next = 0;
 	static int length_of(const uint8_t *program)
 	{
 		int n = 1;
@@ -140,11 +143,16 @@ public:
 		uint64_t dg = 0xcbf29ce484222325ull;
 		for (int i = 0; i < n; ++i)
 			dg = (dg ^ program[i]) * 0x100000001b3ull;
-		if (program_id < 0 || program != last_program || dg != last_digest) {
+		int program_id = -1;
+		for (int k = 0; k < REMEMBERED; ++k)
+			if (ids[k] >= 0 && digests[k] == dg)
+				program_id = ids[k];
+		if (program_id < 0) {
 			program_id = polar_hip_load_program(polar_amd_detail::context(), program, n);
 			polar_amd_detail::check(program_id, "PolarDecoder (program)");
-			last_program = program;
-			last_digest = dg;
+			digests[next] = dg;
+			ids[next] = program_id;
+			next = (next + 1) % REMEMBERED;
 		}
 		polar_amd_detail::check(polar_hip_decode(polar_amd_detail::context(), program_id, (int8_t *)message, (const int8_t *)codeword, W, POLAR_HOST), "PolarDecoder");
 	}

@@ -242,3 +242,16 @@ def test_product_construction_at_other_rates_and_design_points():
             assert int(amb[i]) == c["tie_at_boundary"]
             if not c["tie_at_boundary"]:
                 assert "%016x" % fnv1a64(fro[i]) == c["frozen_fnv"], c
+
+
+def test_reference_caller_mixing_its_helper_with_the_dropin_header():
+    """INTEGRATION.md: testbench.cc keeps simd.hh / polar_helper.hh (it calls PolarHelper::quant) and
+    swaps only lines 18-21 for polar_amd/polar.hh. Compile-only, against the reference headers where
+    they lie; skipped where the reference checkout is absent (the GPU box)."""
+    import subprocess
+
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("/root/reference absent")
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-W", "-Wall", "-I/root/reference", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "cpp", "mixed_caller.cc")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Condense tools/prof_bench.sh output: kernel stats, HBM bytes per batch-sized decode launch
 (FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes
-for 16-byte-per-lane streaming reads on gfx950), and hbm_traffic.json for bench.py."""
+for 16-byte-per-lane streaming reads on gfx950), VALU and LDS utilisation of the decode kernel,
+and hbm_traffic.json for bench.py (copied to profiles/ when the numbers are to be quoted)."""
 import csv
 import glob
 import json
@@ -13,11 +14,15 @@ out = sys.argv[1]
 args = sys.argv[2:]
 
 
-def opt(name, default):
-    return int(args[args.index(name) + 1]) if name in args else default
+def opt(name, default, conv=int):
+    return conv(args[args.index(name) + 1]) if name in args else default
 
 
-frames, fpw, rl = opt("--frames", 1 << 20), opt("--fpw", 0), opt("--lds-level", 0)
+config = opt("--config", "B", str)
+M = {"A": 10, "B": 16, "D": 20}[config]
+frames = opt("--frames", {"A": 1 << 22, "B": 1 << 20, "D": 1 << 16}[config])
+fpw, rl = opt("--fpw", 0), opt("--lds-level", 0)
+kernel_ns = None
 for row in csv.DictReader(open(os.path.join(out, "kernel_stats.csv"))):
     print("%-70s calls %6s avg_ns %14s pct %s" % (row["Name"][:70], row["Calls"], row["AverageNs"], row["Percentage"]))
 vals = defaultdict(list)
@@ -26,14 +31,31 @@ for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), r
         if "sc_decode_kernel" in row.get("Kernel_Name", ""):
             vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {}
-for k, v in vals.items():
-    big = [x for x in v if x >= 0.5 * max(v)]
+for k, v in sorted(vals.items()):
+    big = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v
     res[k] = sum(big) / len(big)
-    print("%s: %d decode dispatches, %d batch-sized, mean %.6g KiB" % (k, len(v), len(big), res[k]))
+    print("%-22s %d decode dispatches, %d batch-sized, mean %.6g" % (k, len(v), len(big), res[k]))
+doc = {"config": config, "frames": frames, "fpw": fpw, "lds_level": rl,
+       "source": "rocprofv3 --pmc, one counter group per run of the same bench command (tools/prof_bench.sh); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled per MI355X_MICROARCH.md"}
 if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     rd, wr = 2 * res["FETCH_SIZE"] * 1024, res["WRITE_SIZE"] * 1024
-    alg = frames * 1.5 * 65536
+    alg = frames * 1.5 * (1 << M)
     print("per launch: read %.4g B (FETCH_SIZE x 2), written %.4g B, total %.4g B = %.1f x the algorithmic %.4g B" % (rd, wr, rd + wr, (rd + wr) / alg, alg))
-    json.dump({"frames": frames, "fpw": fpw, "lds_level": rl, "bytes_per_launch": rd + wr, "read_bytes": rd, "written_bytes": wr,
-               "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (KiB), FETCH_SIZE doubled per MI355X_MICROARCH.md"},
-              open(os.path.join(out, "hbm_traffic.json"), "w"))
+    doc.update(bytes_per_launch=rd + wr, read_bytes=rd, written_bytes=wr)
+if "GRBM_GUI_ACTIVE" in res:
+    cycles = res["GRBM_GUI_ACTIVE"] / 8.0  # the counter is summed over the 8 XCDs
+    doc["kernel_cycles"] = cycles
+    if "SQ_INSTS_VALU" in res:
+        # one wave64 VALU instruction occupies its SIMD for 4 cycles (tools/ubench/valu_rate: 4.1 measured); 256 CUs x 4 SIMDs
+        doc["valu_util"] = res["SQ_INSTS_VALU"] * 4.0 / (cycles * 1024)
+        doc["valu_wave_instructions"] = res["SQ_INSTS_VALU"]
+        print("VALU: %.4g wave-instructions, utilisation %.1f %% of 1024 SIMDs x 1 instruction / 4 cycles" % (res["SQ_INSTS_VALU"], 100 * doc["valu_util"]))
+    if "SQ_LDS_IDX_ACTIVE" in res:
+        # LDS-array cycles over all CUs; one CU moves 256 B per LDS cycle (~150 TB/s chip-wide at 2.4 GHz)
+        doc["lds_bw_util"] = res["SQ_LDS_IDX_ACTIVE"] / (cycles * 256)
+        doc["lds_bank_conflict_frac"] = res.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(1.0, res["SQ_LDS_IDX_ACTIVE"])
+        print("LDS: array active %.2f %% of the CU-cycles, bank-conflict cycles %.2f %% of the active ones" % (100 * doc["lds_bw_util"], 100 * doc["lds_bank_conflict_frac"]))
+    if "SQ_WAVE_CYCLES" in res and "SQ_WAIT_ANY" in res:
+        print("waves: waiting %.1f %% of their cycles (SQ_WAIT_ANY / SQ_WAVE_CYCLES), issuing %.1f %%" % (
+            100 * res["SQ_WAIT_ANY"] / res["SQ_WAVE_CYCLES"], 100 * res.get("SQ_ACTIVE_INST_ANY", 0) / res["SQ_WAVE_CYCLES"]))
+json.dump(doc, open(os.path.join(out, "hbm_traffic.json"), "w"), indent=1, sort_keys=True)
