@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <vector>
 
+#include "construct.hpp"
 #include "sc_core.hpp"
 
 namespace polar {
@@ -55,6 +56,74 @@ inline void fuse_chains(std::vector<DevOp> &ops, int q, int max_depth)
 		DevOp c = {OP_CHAIN | (uint32_t)lvl << 8, ops[i].hrd, 0, pad | (uint32_t)depth};
 		out.push_back(c);
 		i += depth;
+	}
+	ops.swap(out);
+}
+
+// Replace every composite node of level 4, else 3 (left|rate0_right ... comb|rate0_comb|
+// rate1_comb and all nodes in between) by one OP_SUBTREE word carrying the frozen mask of its
+// positions. The device derives the node decomposition from the mask by the compiler's rules, so a
+// node is fused only if compiling its mask gives back exactly its bytes (always the case for
+// programs of PolarCompiler; a hand-made program that decomposes a node differently keeps its ops).
+// ops[i] corresponds to prog[1 + i].
+inline void fuse_subtrees(std::vector<DevOp> &ops, const uint8_t *prog)
+{
+	std::vector<DevOp> out;
+	auto level_of = [](const DevOp &d) { return (int)(d.op_level >> 8); };
+	// the composite node of level L that starts at ops[i]: its last op, or 0 if it cannot be fused
+	auto try_fuse = [&](size_t i, int L, DevOp &fused) -> size_t {
+		size_t e = i + 1; // the comb that completes this node: the first one at level L
+		for (; e < ops.size(); ++e) {
+			uint32_t oe = ops[e].op_level & 255;
+			if ((oe == OP_COMB || oe == OP_RATE0_COMB || oe == OP_RATE1_COMB) && level_of(ops[e]) == L)
+				break;
+		}
+		if (e >= ops.size())
+			return 0;
+		uint8_t frozen[16] = {};
+		const uint32_t base = ops[e].hrd;
+		uint32_t first_row = ~0u;
+		for (size_t k = i; k <= e; ++k) {
+			const uint32_t o = ops[k].op_level & 255, at = ops[k].hrd - base, n = 1u << level_of(ops[k]);
+			bool emits = false;
+			switch (o) {
+			case OP_RATE0: for (uint32_t j = 0; j < n; ++j) frozen[at + j] = 1; break;
+			case OP_REP: for (uint32_t j = 0; j + 1 < n; ++j) frozen[at + j] = 1; emits = true; break;
+			case OP_SPC: frozen[at] = 1; emits = true; break;
+			case OP_RATE1: emits = true; break;
+			case OP_RATE1_COMB: emits = true; break;
+			case OP_RATE0_COMB: for (uint32_t j = 0; j < n / 2; ++j) frozen[at + j] = 1; break;
+			default: break;
+			}
+			if (emits && first_row == ~0u)
+				first_row = ops[k].row;
+		}
+		uint8_t bytes[64]; // would the compiler decompose this mask into these very bytes?
+		ProgramBuilder b;
+		if (b.run(bytes, frozen, L) != (int)(e - i + 1) + 2)
+			return 0;
+		for (size_t k = i; k <= e; ++k)
+			if (bytes[1 + (k - i)] != prog[1 + k])
+				return 0;
+		uint32_t mask = 0;
+		for (int j = 0; j < (1 << L); ++j)
+			mask |= (uint32_t)frozen[j] << j;
+		fused = DevOp{OP_SUBTREE | (uint32_t)L << 8, base, first_row == ~0u ? 0u : first_row, mask};
+		return e;
+	};
+	for (size_t i = 0; i < ops.size();) {
+		const uint32_t o = ops[i].op_level & 255;
+		const int L = level_of(ops[i]);
+		DevOp fused;
+		size_t e = 0;
+		if ((o == OP_LEFT || o == OP_RATE0_RIGHT) && (L == 4 || L == 3))
+			e = try_fuse(i, L, fused);
+		if (e) {
+			out.push_back(fused);
+			i = e + 1;
+		} else {
+			out.push_back(ops[i++]);
+		}
 	}
 	ops.swap(out);
 }
@@ -135,8 +204,15 @@ inline int translate_program(const uint8_t *prog, int length, HostProgram &out, 
 	}
 	if (lvl != top)
 		return 10;
-	if (fuse_q)
+	if (fuse_q) {
+		// Narrow groups are bound by the per-node latency of the small nodes, not by lanes: there one
+		// lane per frame quad decoding a whole level-3 node in registers beats five ops over LDS
+		// (+5...11 % at 8 Ki ... 32 Ki frames); with 32 quads per wavefront the LDS passes keep all 64
+		// lanes busy and the in-register form leaves half of them idle (-7 % at N = 2^10, measured).
+		if (fuse_q <= SUBTREE_MAX_Q)
+			fuse_subtrees(out.ops, prog);
 		fuse_chains(out.ops, fuse_q, max_depth < CHAIN_MAX ? max_depth : (int)CHAIN_MAX);
+	}
 	DevOp e = {OP_END, 0, 0, 0};
 	out.ops.push_back(e);
 	out.ops.push_back(e); // the interpreter fetches one word ahead

@@ -46,9 +46,16 @@ enum : u32 {
 	// device-only: a run of left / right / rate0_right nodes descending level by level, fused by
 	// the host into one pass (program.hpp); `pad` holds depth and stage kinds
 	OP_CHAIN = 16,
+	// device-only: a whole composite node of level SUBTREE_LEVEL (its left / right / comb ops and
+	// every node below them), decoded per frame-quad lane in registers; `pad` = frozen mask of its
+	// positions (bit j = position j frozen), from which the lanes re-derive the compiler's own
+	// node decomposition (polar_compiler.hh:26-48); the host fuses only where that derivation
+	// reproduces the program's bytes (program.hpp)
+	OP_SUBTREE = 17,
 	OP_END = 255
 };
 enum { CHAIN_MAX = 4 }; // per kernel variant: Group::CHAIN_DEPTH
+enum { SUBTREE_LEVEL = 3, SUBTREE_MAX_Q = 16 }; // OP_SUBTREE roots: level 3 (one plane octet) and level 4 (two)
 // DevOp.pad of OP_CHAIN: bits 0-2 depth D, bits 3-4 kind of stage 1 (0 = f, 1 = g, 2 = qadd),
 // bit 4+k kind of stage k >= 2 (0 = f, 1 = qadd), bit 12+k: output of stage k is not stored (it
 // only feeds a rate0_right stage of the same chain)
@@ -819,6 +826,148 @@ struct Group {
 		wave_sync();
 	}
 
+	// ---- composite nodes of at most 8 elements, one lane per frame quad, everything in registers ----
+	// x: the node's 2^L LLR dwords; fm: frozen mask (bit j = position j). Returns the node's decisions
+	// as normalised planes (element j at bit 7-j of every byte, other bits clear) and emits its
+	// message rows from `row` on. The case order is the compiler's (polar_compiler.hh:26-48), the
+	// node functions are polar_decoder.hh:28-127; a left ... rate1_comb node is the same g pass
+	// followed by a rate-1 right child and the comb.
+	template <int L>
+	PDEV void reg_subtree(u32 (&x)[1 << L], u32 fm, u32 &s, u32 &z, u32 &row, int q) const
+	{
+		constexpr int len = 1 << L, half = len / 2;
+		constexpr u32 all = (1u << len) - 1u, lo = (1u << half) - 1u;
+		fm &= all;
+		const u32 l = (u32)__builtin_popcount(fm & lo), r = (u32)__builtin_popcount(fm >> half);
+		s = z = 0;
+		if (l == (u32)half && r == (u32)half) // rate0: all +1
+			return;
+		if (!l && !r) { // rate1
+#pragma unroll
+			for (int j = 0; j < len; ++j) {
+				s |= (x[j] & SIGN_BITS) >> j;
+				z |= zero_bytes(x[j]) >> j;
+			}
+			u32 ts = s, tz = z;
+			trans_octet(ts, tz, len);
+			emit_octet(ts, tz, len, 0, row, q);
+			row += len;
+			return;
+		}
+		if (l == (u32)half && r == (u32)half - 1 && !((fm >> (len - 1)) & 1u)) { // rep: pairwise halving sums
+#pragma unroll
+			for (int h = half; h >= 1; h /= 2)
+#pragma unroll
+				for (int i = 0; i < h; ++i)
+					x[i] = qadd4(x[i], x[i + h]);
+			const u32 zb = zero_bytes(x[0]), m = span_mask(0, len);
+			s = byte_mask(x[0]) & m;
+			z = byte_mask(zb) & m;
+			out.st(row, q, symbols(x[0], zb));
+			row += 1;
+			return;
+		}
+		if (l == 1 && !r && (fm & 1u)) { // spc: every position tied for the minimum takes the parity
+			u32 mh = 0x7F007F00u, ml = 0x7F007F00u;
+#pragma unroll
+			for (int j = 0; j < len; ++j) {
+				s |= (x[j] & SIGN_BITS) >> j;
+				mh = pk_min(mh, abs_half(split_hi(x[j])));
+				ml = pk_min(ml, abs_half(split_lo(x[j])));
+			}
+			const u32 odd = odd_mask(s);
+			if (odd) {
+				u32 tie = 0;
+#pragma unroll
+				for (int j = 0; j < len; ++j)
+					tie |= tie_bits(x[j], mh, ml) >> j;
+				s ^= tie & odd;
+			}
+			u32 ts = s, tz = 0;
+			trans_octet(ts, tz, len);
+			emit_octet(ts, tz, len, 1, row, q);
+			row += len - 1;
+			return;
+		}
+		if constexpr (L > 1) {
+			u32 y[half], cs, cz;
+			if (l == (u32)half) { // rate0_right, child, rate0_comb
+#pragma unroll
+				for (int i = 0; i < half; ++i)
+					y[i] = qadd4(x[i], x[i + half]);
+				reg_subtree<L - 1>(y, fm >> half, cs, cz, row, q);
+				s = cs | (cs >> half);
+				z = cz | (cz >> half);
+				return;
+			}
+#pragma unroll
+			for (int i = 0; i < half; ++i) // left
+				y[i] = prod4(x[i], x[i + half]);
+			reg_subtree<L - 1>(y, fm, cs, cz, row, q);
+#pragma unroll
+			for (int i = 0; i < half; ++i) // right
+				y[i] = madd4(cs << i, cz << i, x[i], x[i + half]);
+			u32 rs, rz;
+			reg_subtree<L - 1>(y, fm >> half, rs, rz, row, q);
+			const u32 m = span_mask(0, half); // comb
+			s = ((cs ^ rs) & m) | (rs >> half);
+			z = ((cz | rz) & m) | (rz >> half);
+		}
+	}
+	template <class SRC>
+	PDEV void subtree_from(int lvl, const SRC &src, u32 hrd, u32 row, u32 fm)
+	{
+		Planes<lds_u32> p = lplanes(hrd);
+		PFOR_LANES(lane) {
+			if (lane < Q) {
+				int q = lane, i = pidx(p.eb, q);
+				u32 r = row;
+				if (lvl == 3) {
+					u32 x[8], s, z;
+#pragma unroll
+					for (int j = 0; j < 8; ++j)
+						x[j] = src.ld(j * Q + q);
+					reg_subtree<3>(x, fm, s, z, r, q);
+					put_bits(p, i, 0, 8, s, z);
+				} else { // level 4: a composite root over two level-3 children, one plane octet each
+					u32 x[16], y[8], ls, lz, rs, rz;
+#pragma unroll
+					for (int j = 0; j < 16; ++j)
+						x[j] = src.ld(j * Q + q);
+					if (__builtin_popcount(fm & 0xFFu) == 8) { // rate0_right, child, rate0_comb
+#pragma unroll
+						for (int j = 0; j < 8; ++j)
+							y[j] = qadd4(x[j], x[j + 8]);
+						reg_subtree<3>(y, fm >> 8, rs, rz, r, q);
+						ls = rs;
+						lz = rz;
+					} else {
+#pragma unroll
+						for (int j = 0; j < 8; ++j)
+							y[j] = prod4(x[j], x[j + 8]);
+						reg_subtree<3>(y, fm, ls, lz, r, q);
+#pragma unroll
+						for (int j = 0; j < 8; ++j)
+							y[j] = madd4(ls << j, lz << j, x[j], x[j + 8]);
+						reg_subtree<3>(y, fm >> 8, rs, rz, r, q);
+						ls ^= rs;
+						lz |= rz;
+					}
+					put_bits(p, i, 0, 8, ls, lz);
+					put_bits(p, i + Q, 0, 8, rs, rz);
+				}
+			}
+		}
+		wave_sync();
+	}
+	PDEV void subtree(int lvl, u32 hrd, u32 row, u32 fm)
+	{
+		if (lvl == top)
+			subtree_from(lvl, in, hrd, row, fm);
+		else
+			subtree_from(lvl, LVec{sl + (Q << lvl)}, hrd, row, fm);
+	}
+
 	// one or two butterfly stages (octet distance ho, and 2*ho when TWO) of the transform on one
 	// plane array of noct*Q dwords; OR instead of XOR for the zero plane
 	template <bool TWO, bool IS_OR, class E, class T>
@@ -1297,6 +1446,10 @@ struct Group {
 	{
 		switch (op) {
 		case OP_CHAIN: chain(lvl, hrd, pad); break;
+		case OP_SUBTREE: // compiled only into the narrow-group kernels the host emits it for (program.hpp)
+			if constexpr (Q <= SUBTREE_MAX_Q)
+				subtree(lvl, hrd, row, pad);
+			break;
 		case OP_COMB: comb_any<false>(lvl, hrd); break;
 		case OP_RATE0_COMB: comb_any<true>(lvl, hrd); break;
 		case OP_RATE1_COMB: rate1_comb_any(lvl, hrd, row); break;

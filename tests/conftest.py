@@ -58,13 +58,14 @@ def emu():
 
     so = os.path.join(ROOT, "tests", "emu", "libemu.so")
     src = os.path.join(ROOT, "tests", "emu", "emu_decode.cc")
-    deps = [src] + [os.path.join(ROOT, "polar_amd", "csrc", f) for f in ("sc_core.hpp", "program.hpp")]
+    deps = [src] + [os.path.join(ROOT, "polar_amd", "csrc", f) for f in ("sc_core.hpp", "program.hpp", "construct.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-shared", "-fPIC", "-o", so, src], check=True)
     E = ctypes.CDLL(so)
     E.emu_decode.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_size_t, ctypes.c_int, ctypes.c_int]
     E.emu_op.argtypes = [ctypes.c_int] + [ctypes.c_uint] * 4
     E.emu_op.restype = ctypes.c_uint
+    E.emu_op_count.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     return E
 
 

@@ -125,3 +125,16 @@ extern "C" unsigned emu_op(int which, unsigned a, unsigned b, unsigned hs, unsig
 	}
 	return 0;
 }
+
+// number of device instruction words with opcode `opcode` (any if < 0) after translation for a
+// wavefront of q frame quads: lets the tests see that the host-side fusions took place
+extern "C" int emu_op_count(const uint8_t *prog, int len, int q, int opcode)
+{
+	HostProgram hp;
+	if (translate_program(prog, len, hp, q, CHAIN_MAX))
+		return -1;
+	int n = 0;
+	for (const DevOp &d : hp.ops)
+		n += (d.op_level & 255) != OP_END && (opcode < 0 || (int)(d.op_level & 255) == opcode);
+	return n;
+}

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
-from inputs import corner_frames, family_llr, pm1_message
+from inputs import corner_frames, family_llr, pm1_message, rand_bytes
 from oracle_lib import fnv1a64
 
 
@@ -255,3 +255,25 @@ def test_reference_caller_mixing_its_helper_with_the_dropin_header():
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-W", "-Wall", "-I/root/reference", "-I" + os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "tests", "cpp", "mixed_caller.cc")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_subtree_fusion_takes_place(emu, oracle):
+    """program.hpp fuse_subtrees: in the N = 2^16 bench code every composite level-3 node becomes one
+    in-register OP_SUBTREE word (17) and the device program shrinks accordingly; a hand-made program
+    that decomposes a node differently from the compiler is left alone and still decodes right."""
+    M = 16
+    fro, _ = oracle.const0(M, 1 << (M - 1))
+    prog = oracle.compile(fro, M)
+    total = emu.emu_op_count(prog.ctypes.data, prog.size, 8, -1)
+    sub = emu.emu_op_count(prog.ctypes.data, prog.size, 8, 17)
+    assert sub > 400 and total < 3500, (total, sub)
+    assert emu.emu_op_count(prog.ctypes.data, prog.size, 32, 17) == 0  # wide groups keep the LDS passes (program.hpp)
+    # level-3 node [1,1,1,0, 1,0,0,0]: the compiler writes 0,5,1,6,2 (left rep right spc comb); the same
+    # frozen set decomposed one level further on the right (spc at level 2 -> left, rep, right, rate1, comb at level 1/2)
+    handmade = np.array([3, 0, 5, 1, 0, 5, 1, 4, 2, 2, 255], np.uint8)
+    assert emu.emu_op_count(handmade.ctypes.data, handmade.size, 4, 17) == 0
+    llr = rand_bytes(5, (8, 48)).view(np.int8)
+    assert (_emu_decode(emu, llr, handmade, 4, 4) == oracle.decode(llr, handmade)).all()
+    compiled = np.array([3, 0, 5, 1, 6, 2, 255], np.uint8)
+    assert emu.emu_op_count(compiled.ctypes.data, compiled.size, 4, 17) == 1
+    assert (_emu_decode(emu, llr, compiled, 4, 4) == oracle.decode(llr, compiled)).all()
