@@ -1,9 +1,11 @@
 // polar_hip.hip -- kernels and C ABI of libpolar_hip.so (gfx950 only).
 //
-//   sc_decode_kernel   : batched SC decoder, one wavefront per group of 4*Q frames
-//                        (sc_core.hpp; replaces PolarDecoder::operator(), polar_decoder.hh:131)
-//   butterfly_kernel   : polar transform stages for the encoders (polar_encoder.hh:15-58)
+//   sc_decode_kernel        : batched SC decoder, one wavefront per group of 4*Q frames (decode_kernel.hpp,
+//                             sc_core.hpp, variants.hip; replaces PolarDecoder::operator(), polar_decoder.hh:131)
+//   sc_decode_f32_kernel    : the reference's float helper per lane (polar_helper.hh:62-111)
+//   butterfly_kernel        : polar transform stages for the encoders (polar_encoder.hh:15-58)
 //   packed_transform_kernel : systematic extraction = re-encode + gather on bit-packed symbols (testbench.cc:177-183)
+//   channel_kernel, count_kernel : the bench's message source, AWGN channel and error counters (testbench.cc:112-192)
 //
 // Everything here fails loudly: there is no CPU fallback for any device entry point.
 #include <hip/hip_runtime.h>
