@@ -824,7 +824,8 @@ static size_t scratch_bytes_per_wave(int q, int top)
 // Default shape: the 20 KiB-of-LDS family (8 wavefronts per CU), widest first. 128 frames per
 // wavefront measured best at N = 2^16; narrower groups when the batch is too small
 // to give every resident wavefront a group, or when the scratch arenas would not fit.
-// Scratch budget: what the handle holds already plus half of the free device memory. The query
+// Scratch budget: what the handle holds already plus 5/8 of the free device memory (so that
+// N = 2^20 with 2^16 frames gets its 80 GiB of (32, 8) arenas beside 128 GiB of caller data). The query
 // is slow (milliseconds), so it is made only when a request exceeds what is held.
 struct ScratchBudget {
 	const polar_hip_handle *h;
@@ -842,7 +843,7 @@ struct ScratchBudget {
 			size_t free_b = 0, total_b = 0;
 			if (hipMemGetInfo(&free_b, &total_b) != hipSuccess)
 				free_b = 0;
-			cap = h->scratch.bytes + free_b / 2;
+			cap = h->scratch.bytes + free_b / 8 * 5;
 			queried = true;
 		}
 		return cap;
