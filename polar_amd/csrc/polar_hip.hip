@@ -358,8 +358,10 @@ struct PackedPass {
 	u32 *out_sign, *out_eras; // last pass: [K][cols] bit planes (sign, erasure), or null
 	const int *src_row;    // [N]: message row of a code position, -1 = frozen
 	size_t frames, cols;
-	int level, s0, first, last, wide;
+	int level, s0, first, last, wide; // first: PACK_LOAD_*, last: PACK_STORE_*
 };
+enum { PACK_LOAD_TMP = 0, PACK_LOAD_MESSAGE = 1, PACK_LOAD_REFREEZE = 2 }; // refreeze: tmp, with +1 at the frozen positions (polar_encoder.hh:46-48)
+enum { PACK_STORE_TMP = 0, PACK_STORE_INFO = 1, PACK_STORE_ALL = 2 };      // info rows gathered to [K][...]; all rows as symbols to out[N][frames]
 
 template <int C>
 __global__ void __launch_bounds__(256) packed_transform_kernel(PackedPass a)
@@ -379,13 +381,15 @@ __global__ void __launch_bounds__(256) packed_transform_kernel(PackedPass a)
 		{
 			const size_t row = row0 + ((size_t)k << a.s0);
 			PackedRow r;
-			if (a.first) {
+			if (a.first != PACK_LOAD_TMP) {
 				int src = a.src_row[row];
 				if (src < 0) {
 					r.neg = 0u;
 					r.nz = valid;
-				} else {
+				} else if (a.first == PACK_LOAD_MESSAGE) {
 					r = pack_symbols(a.msg + (size_t)src * a.frames, f0, a.frames, a.wide);
+				} else {
+					r = a.tmp[row * a.cols + col];
 				}
 			} else {
 				r = a.tmp[row * a.cols + col];
@@ -410,8 +414,12 @@ __global__ void __launch_bounds__(256) packed_transform_kernel(PackedPass a)
 		{
 			const size_t row = row0 + ((size_t)k << a.s0);
 			PackedRow r = {neg[k] & nz[k], nz[k]};
-			if (!a.last) {
+			if (a.last == PACK_STORE_TMP) {
 				a.tmp[row * a.cols + col] = r;
+				continue;
+			}
+			if (a.last == PACK_STORE_ALL) {
+				unpack_symbols(a.out + row * a.frames, f0, a.frames, a.wide, r);
 				continue;
 			}
 			int dst = a.src_row[row];
@@ -1259,8 +1267,14 @@ static int transform_passes(polar_hip_handle *h, T *cw, const T *msg, const int 
 }
 
 // codeword (device, N x frames) <- encode(message (device, K x frames))
+static int encode_packed(polar_hip_handle *h, int systematic, int8_t *cw, const int8_t *msg, int level, size_t frames);
+
 static int encode_device(polar_hip_handle *h, int systematic, int8_t *cw, const int8_t *msg, int level, size_t frames)
 {
+	static const bool bytes_only = getenv("POLAR_HIP_ENCODE_BYTES") != nullptr; // experiments only
+	if (frames % 32 == 0 && (uintptr_t)cw % 16 == 0 && (uintptr_t)msg % 16 == 0 && !bytes_only)
+		return encode_packed(h, systematic, cw, msg, level, frames);
+	// ragged batches and unaligned buffers: byte symbols in place
 	const int *src_row = (const int *)h->tables.p;
 	bool wide = frames % 4 == 0 && (uintptr_t)cw % 4 == 0 && (uintptr_t)msg % 4 == 0;
 	int rc;
@@ -1328,28 +1342,22 @@ static int pack_cmax()
 static size_t packed_cols(size_t frames) { return (frames + 31) / 32; }
 static size_t packed_tmp_bytes(int level, size_t frames) { return level > pack_cmax() ? ((size_t)1 << level) * packed_cols(frames) * sizeof(PackedRow) : 0; }
 
-static int extract_device(polar_hip_handle *h, int8_t *out, u32 *out_sign, u32 *out_eras, const int8_t *decoded, void *tmp, int level, size_t frames)
+// one transform over packed rows: `load` for the first pass, `store` for the last one
+static int packed_transform(polar_hip_handle *h, PackedPass a, int level, int load, int store, uint8_t *out, u32 *out_sign, u32 *out_eras, const char *who)
 {
-	PackedPass a;
-	a.tmp = (PackedRow *)tmp;
-	a.msg = (const uint8_t *)decoded;
-	a.src_row = (const int *)h->tables.p;
-	a.frames = frames;
-	a.cols = packed_cols(frames);
-	a.level = level;
-	a.wide = frames % 32 == 0 && (uintptr_t)decoded % 16 == 0 && (uintptr_t)out % 16 == 0;
 	const int passes = (level + pack_cmax() - 1) / pack_cmax();
 	for (int s0 = 0, pass = 0; s0 < level; ++pass) {
 		int c = (level - s0 + (passes - pass) - 1) / (passes - pass); // what is left, spread over the passes left
+		bool last = s0 + c >= level;
 		a.s0 = s0;
-		a.first = s0 == 0;
-		a.last = s0 + c >= level;
-		a.out = a.last ? (uint8_t *)out : nullptr;
-		a.out_sign = a.last ? out_sign : nullptr;
-		a.out_eras = a.last ? out_eras : nullptr;
+		a.first = s0 == 0 ? load : PACK_LOAD_TMP;
+		a.last = last ? store : PACK_STORE_TMP;
+		a.out = last ? out : nullptr;
+		a.out_sign = last ? out_sign : nullptr;
+		a.out_eras = last ? out_eras : nullptr;
 		size_t items = (((size_t)1 << level) >> c) * a.cols, blocks = (items + 255) / 256;
 		if (blocks > 0x7FFFFFFFu)
-			return fail(POLAR_E_ARG, "polar_hip_systematic_extract: too many frames for one call");
+			return fail(POLAR_E_ARG, std::string(who) + ": too many frames for one call");
 		switch (c) {
 		case 1: hipLaunchKernelGGL(packed_transform_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, h->stream, a); break;
 		case 2: hipLaunchKernelGGL(packed_transform_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, h->stream, a); break;
@@ -1362,6 +1370,41 @@ static int extract_device(polar_hip_handle *h, int8_t *out, u32 *out_sign, u32 *
 		s0 += c;
 	}
 	return POLAR_OK;
+}
+
+static int extract_device(polar_hip_handle *h, int8_t *out, u32 *out_sign, u32 *out_eras, const int8_t *decoded, void *tmp, int level, size_t frames)
+{
+	PackedPass a = {};
+	a.tmp = (PackedRow *)tmp;
+	a.msg = (const uint8_t *)decoded;
+	a.src_row = (const int *)h->tables.p;
+	a.frames = frames;
+	a.cols = packed_cols(frames);
+	a.level = level;
+	a.wide = frames % 32 == 0 && (uintptr_t)decoded % 16 == 0 && (uintptr_t)out % 16 == 0;
+	return packed_transform(h, a, level, PACK_LOAD_MESSAGE, PACK_STORE_INFO, (uint8_t *)out, out_sign, out_eras, "polar_hip_systematic_extract");
+}
+
+// Encoders on packed rows (whole 32-frame columns, 16-byte aligned buffers): K bytes in, N bytes
+// out and N/4 bytes per intermediate pass instead of N in and out per pass of butterfly_kernel.
+static int encode_packed(polar_hip_handle *h, int systematic, int8_t *cw, const int8_t *msg, int level, size_t frames)
+{
+	PackedPass a = {};
+	a.msg = (const uint8_t *)msg;
+	a.src_row = (const int *)h->tables.p;
+	a.frames = frames;
+	a.cols = packed_cols(frames);
+	a.level = level;
+	a.wide = 1;
+	int rc = h->enc_tmp.reserve(((size_t)1 << level) * a.cols * sizeof(PackedRow) + 16);
+	if (rc)
+		return rc;
+	a.tmp = (PackedRow *)h->enc_tmp.p;
+	if (!systematic)
+		return packed_transform(h, a, level, PACK_LOAD_MESSAGE, PACK_STORE_ALL, (uint8_t *)cw, nullptr, nullptr, "polar_hip_encode");
+	if ((rc = packed_transform(h, a, level, PACK_LOAD_MESSAGE, PACK_STORE_TMP, nullptr, nullptr, nullptr, "polar_hip_encode")))
+		return rc;
+	return packed_transform(h, a, level, PACK_LOAD_REFREEZE, PACK_STORE_ALL, (uint8_t *)cw, nullptr, nullptr, "polar_hip_encode");
 }
 
 // shared body of polar_hip_systematic_extract and polar_hip_systematic_extract_packed

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _code(oracle, M, code="const0", K=None):
     N = 1 << M
     if code == "const0":
-        fro, _ = oracle.const0(M, K or N // 2)
+        fro, _ = oracle.const0(M, N // 2 if K is None else K)
         return fro
     return oracle.freezer(M, 0.5, 0.5)[0]
 
@@ -262,6 +262,18 @@ def test_encoders(session, oracle, golden):
             cw = np.zeros((1 << M, frames), np.int8)
             (polar_amd.PolarSysEnc if sysf else polar_amd.PolarEncoder)(M, session)(cw, msg, fro)
             assert (cw == oracle.encode(msg, fro, M, sysf)).all(), (M, sysf)
+    # whole 32-frame columns go through the bit-packed passes: ternary symbols, codes of one
+    # pass and of several, K = 0 and K = N, and the byte path beside it (frames not a multiple of 32)
+    rng = np.random.default_rng(5)
+    for M in (1, 2, 5, 6, 10, 11, 13):
+        for K in sorted({0, 1, (1 << M) // 3, 1 << M}):
+            fro = _code(oracle, M, K=K)
+            for frames in (64, 36):
+                msg = rng.integers(-1, 2, (max(K, 1), frames)).astype(np.int8)[:K]
+                for sysf in (0, 1):
+                    cw = np.zeros((1 << M, frames), np.int8)
+                    (polar_amd.PolarSysEnc if sysf else polar_amd.PolarEncoder)(M, session)(cw, msg, fro)
+                    assert (cw == oracle.encode(msg, fro, M, sysf)).all(), (M, K, frames, sysf)
 
 
 def test_systematic_chain(session, oracle):
