@@ -109,8 +109,19 @@ int polar_hip_code(polar_hip_handle *h, int level, int K, long double erasure_pr
 
 /* PolarDecoder<TYPE,MAX_M>::operator()(message, codeword, program) polar_decoder.hh:131-464
  * for `frames` frames at once. codeword: N x frames int8 LLRs (not modified);
- * message: K x frames int8 decisions. `where` says whether both pointers are host or device. */
+ * message: K x frames int8 decisions. `where` says whether both pointers are host or device.
+ * Host buffers are staged over PCIe: whole and one after the other when they are pageable; in
+ * chunks of about 1 GiB of LLRs (at least 16384 frames), copy-in / decode / copy-out overlapped,
+ * when both are page-locked (polar_hip_host_alloc, hipHostMalloc, hipHostRegister) and hold at
+ * least two chunks. */
 int polar_hip_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, int where);
+
+/* Page-locked host memory for frame buffers, in place of the aligned_alloc of
+ * testbench.cc:72,92-93,100-103, so that polar_hip_decode takes the overlapped path above
+ * (hipHostMalloc / hipHostFree for callers that do not include HIP headers; 4 KiB aligned).
+ * NULL when the memory cannot be had. No counterpart in the reference. */
+void *polar_hip_host_alloc(size_t bytes);
+void polar_hip_host_free(void *ptr);
 /* Same, enqueued on `stream` (a hipStream_t) without synchronising; device pointers only. A
  * handle owns one scratch arena: keep its launches on one stream (any mix of programs).
  * The first launch of a program with a new wavefront shape uploads its instruction stream, and

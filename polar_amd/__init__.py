@@ -9,6 +9,7 @@ no CPU fallback: importing it without the built library raises.
 from .api import (  # noqa: F401
     DEVICE,
     HOST,
+    HostBuffer,
     PolarCodeConst0,
     PolarCompiler,
     PolarDecoder,

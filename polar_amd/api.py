@@ -49,6 +49,30 @@ def _where(*ws):
     return ws[0] if ws else HOST
 
 
+class HostBuffer:
+    """Page-locked host memory as a numpy array (polar_hip_host_alloc): frame buffers that
+    PolarDecoder copies over PCIe while it decodes. `array` is valid until close()."""
+
+    def __init__(self, shape, dtype=np.int8):
+        nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = lib.polar_hip_host_alloc(max(nbytes, 1))
+        if not self._p:
+            raise PolarError(-4, "polar_hip_host_alloc")
+        self.array = np.ctypeslib.as_array((ctypes.c_uint8 * max(nbytes, 1)).from_address(self._p))[:nbytes].view(dtype).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib.polar_hip_host_free(ctypes.c_void_p(self._p))
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def testbench_probability():
     """Erasure probability the reference bench feeds PolarCodeConst0 for rate 1/2 (testbench.cc:74-87)."""
     import math

@@ -577,6 +577,12 @@ struct polar_hip_handle {
 	hipStream_t own_stream = nullptr; // created with the handle
 	hipStream_t stream = nullptr;     // where the synchronous entry points enqueue: own_stream or the caller's (polar_hip_set_stream)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	// host-buffer pipeline (polar_hip_decode with pinned POLAR_HOST buffers): copy-in and copy-out
+	// streams beside `stream`, and per staging slot the events "copied in", "decoded", "copied out"
+	hipStream_t pipe_in = nullptr, pipe_out = nullptr;
+	hipEvent_t pipe_ev[2][3] = {};
+	void *bounce_in = nullptr, *bounce_out = nullptr; // page-locked staging for pageable caller buffers, two slots each
+	size_t bounce_in_bytes = 0, bounce_out_bytes = 0;
 	std::map<const void *, int> occupancy; // resident workgroups per CU, per kernel variant
 	bool timed = false;
 	std::vector<LoadedProgram> programs;
@@ -765,6 +771,17 @@ extern "C" void polar_hip_destroy(polar_hip_handle *h)
 	h->sim_dec.release();
 	(void)hipEventDestroy(h->ev0);
 	(void)hipEventDestroy(h->ev1);
+	if (h->bounce_in)
+		(void)hipHostFree(h->bounce_in);
+	if (h->bounce_out)
+		(void)hipHostFree(h->bounce_out);
+	if (h->pipe_in) {
+		(void)hipStreamDestroy(h->pipe_in);
+		(void)hipStreamDestroy(h->pipe_out);
+		for (auto &slot : h->pipe_ev)
+			for (hipEvent_t e : slot)
+				(void)hipEventDestroy(e);
+	}
 	(void)hipStreamDestroy(h->own_stream);
 	delete h;
 }
@@ -1042,6 +1059,193 @@ static int check_decode_args(polar_hip_handle *h, int program_id, const void *me
 	return POLAR_OK;
 }
 
+// True when the runtime knows `p` as page-locked host memory (polar_hip_host_alloc, hipHostMalloc,
+// hipHostRegister): only then do asynchronous copies run beside the host thread.
+static bool host_pinned(const void *p)
+{
+	hipPointerAttribute_t attr;
+	if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+		(void)hipGetLastError(); // pageable memory is "invalid value" to this query
+		return false;
+	}
+	return attr.type == hipMemoryTypeHost;
+}
+
+// frames per chunk of the host-buffer pipeline: about 1 GiB of LLRs, never so few frames that the
+// decode of a chunk falls into the small-batch regime, whole groups of every kernel shape
+static size_t pipeline_chunk(size_t n)
+{
+	if (const char *e = getenv("POLAR_HIP_HOST_CHUNK")) { // frames; tests and experiments only
+		size_t c = (size_t)atoll(e);
+		return c < 512 ? 512 : c - c % 512;
+	}
+	size_t c = ((size_t)1 << 30) / n;
+	if (c < 16384)
+		c = 16384;
+	return c - c % 512;
+}
+
+extern "C" void *polar_hip_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		fail(POLAR_E_NOMEM, "polar_hip_host_alloc: no page-locked memory of that size");
+		return nullptr;
+	}
+	return p;
+}
+
+extern "C" void polar_hip_host_free(void *ptr)
+{
+	if (ptr)
+		(void)hipHostFree(ptr);
+}
+
+enum { COPIED_IN = 0, DECODED = 1, COPIED_OUT = 2 }; // pipe_ev[slot][...]
+
+static int pipeline_setup(polar_hip_handle *h, size_t n, size_t rows, size_t chunk)
+{
+	if (!h->pipe_in) {
+		HIP_TRY(hipStreamCreateWithFlags(&h->pipe_in, hipStreamNonBlocking));
+		HIP_TRY(hipStreamCreateWithFlags(&h->pipe_out, hipStreamNonBlocking));
+		for (auto &slot : h->pipe_ev)
+			for (hipEvent_t &e : slot)
+				HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+	}
+	int rc;
+	if ((rc = h->stage_in.reserve(2 * n * chunk)) || (rc = h->stage_out.reserve(2 * (rows ? rows : 1) * chunk)))
+		return rc;
+	return POLAR_OK;
+}
+
+// rows [0, count) split over a few host threads
+template <class F>
+static void parallel_rows(size_t count, F fn)
+{
+	static const unsigned want = [] {
+		const char *e = getenv("POLAR_HIP_HOST_THREADS");
+		unsigned t = e ? (unsigned)atoi(e) : std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+		return t < 1 ? 1u : t;
+	}();
+	unsigned threads = (unsigned)std::min<size_t>(want, count ? count : 1);
+	std::vector<std::thread> pool;
+	for (unsigned t = 1; t < threads; ++t)
+		pool.emplace_back([=] { fn(count * t / threads, count * (t + 1) / threads); });
+	fn(0, count / threads);
+	for (auto &th : pool)
+		th.join();
+}
+
+// Pageable host buffers, several chunks' worth of frames: the column block of a chunk is gathered
+// by host threads into a page-locked slot, copied in, decoded and copied out asynchronously, and
+// scattered back into the caller's rows while the next chunk is on its way.
+static int decode_host_staged(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, size_t chunk)
+{
+	const HostProgram &hp = h->programs[program_id].host;
+	const size_t n = (size_t)1 << hp.top, rows = hp.rows;
+	int rc;
+	if ((rc = pipeline_setup(h, n, rows, chunk)))
+		return rc;
+	if (h->bounce_in_bytes < 2 * n * chunk) {
+		if (h->bounce_in)
+			(void)hipHostFree(h->bounce_in);
+		h->bounce_in = nullptr;
+		h->bounce_in_bytes = 0;
+		HIP_TRY(hipHostMalloc(&h->bounce_in, 2 * n * chunk, hipHostMallocDefault));
+		h->bounce_in_bytes = 2 * n * chunk;
+	}
+	if (rows && h->bounce_out_bytes < 2 * rows * chunk) {
+		if (h->bounce_out)
+			(void)hipHostFree(h->bounce_out);
+		h->bounce_out = nullptr;
+		h->bounce_out_bytes = 0;
+		HIP_TRY(hipHostMalloc(&h->bounce_out, 2 * rows * chunk, hipHostMallocDefault));
+		h->bounce_out_bytes = 2 * rows * chunk;
+	}
+	const size_t chunks = (frames + chunk - 1) / chunk;
+	for (size_t i = 0; i <= chunks; ++i) {
+		const int b = (int)(i & 1);
+		if (i < chunks) {
+			const size_t f0 = i * chunk, c = frames - f0 < chunk ? frames - f0 : chunk;
+			int8_t *hin = (int8_t *)h->bounce_in + b * n * chunk, *hout = (int8_t *)h->bounce_out + b * rows * chunk;
+			int8_t *din = (int8_t *)h->stage_in.p + b * n * chunk, *dout = (int8_t *)h->stage_out.p + b * rows * chunk;
+			if (i >= 2) // the slot's previous chunk has left the page-locked buffer
+				HIP_TRY(hipEventSynchronize(h->pipe_ev[b][COPIED_IN]));
+			parallel_rows(n, [=](size_t r0, size_t r1) {
+				for (size_t r = r0; r < r1; ++r)
+					memcpy(hin + r * c, codeword + r * frames + f0, c);
+			});
+			if (i >= 2)
+				HIP_TRY(hipStreamWaitEvent(h->pipe_in, h->pipe_ev[b][DECODED], 0));
+			HIP_TRY(hipMemcpyAsync(din, hin, n * c, hipMemcpyHostToDevice, h->pipe_in));
+			HIP_TRY(hipEventRecord(h->pipe_ev[b][COPIED_IN], h->pipe_in));
+			HIP_TRY(hipStreamWaitEvent(h->stream, h->pipe_ev[b][COPIED_IN], 0));
+			if (i >= 2 && rows)
+				HIP_TRY(hipStreamWaitEvent(h->stream, h->pipe_ev[b][COPIED_OUT], 0));
+			if ((rc = launch_decode(h, program_id, dout, din, c, h->stream, true)))
+				return rc;
+			HIP_TRY(hipEventRecord(h->pipe_ev[b][DECODED], h->stream));
+			if (rows) { // the slot's previous messages were scattered in the iteration before this one
+				HIP_TRY(hipStreamWaitEvent(h->pipe_out, h->pipe_ev[b][DECODED], 0));
+				HIP_TRY(hipMemcpyAsync(hout, dout, rows * c, hipMemcpyDeviceToHost, h->pipe_out));
+				HIP_TRY(hipEventRecord(h->pipe_ev[b][COPIED_OUT], h->pipe_out));
+			}
+		}
+		if (i >= 1 && rows) {
+			const int pb = (int)((i - 1) & 1);
+			const size_t f0 = (i - 1) * chunk, c = frames - f0 < chunk ? frames - f0 : chunk;
+			const int8_t *hout = (const int8_t *)h->bounce_out + pb * rows * chunk;
+			HIP_TRY(hipEventSynchronize(h->pipe_ev[pb][COPIED_OUT]));
+			parallel_rows(rows, [=](size_t r0, size_t r1) {
+				for (size_t r = r0; r < r1; ++r)
+					memcpy(message + r * frames + f0, hout + r * c, c);
+			});
+		}
+	}
+	HIP_TRY(hipStreamSynchronize(h->pipe_in));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(hipStreamSynchronize(h->pipe_out));
+	return POLAR_OK;
+}
+
+// Page-locked host buffers, several chunks' worth of frames: chunk i+1 is copied in and chunk i-1
+// copied out while chunk i decodes (three streams, two staging slots, column blocks of the
+// [rows][frames] matrices as 2D copies).
+static int decode_host_pipelined(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, size_t chunk)
+{
+	const HostProgram &hp = h->programs[program_id].host;
+	const size_t n = (size_t)1 << hp.top, rows = hp.rows;
+	int rc;
+	if ((rc = pipeline_setup(h, n, rows, chunk)))
+		return rc;
+	size_t i = 0;
+	for (size_t f0 = 0; f0 < frames; f0 += chunk, ++i) {
+		const size_t c = frames - f0 < chunk ? frames - f0 : chunk;
+		const int b = (int)(i & 1);
+		int8_t *din = (int8_t *)h->stage_in.p + b * n * chunk, *dout = (int8_t *)h->stage_out.p + b * rows * chunk;
+		if (i >= 2) // the slot's previous chunk has been decoded
+			HIP_TRY(hipStreamWaitEvent(h->pipe_in, h->pipe_ev[b][DECODED], 0));
+		HIP_TRY(hipMemcpy2DAsync(din, c, codeword + f0, frames, c, n, hipMemcpyHostToDevice, h->pipe_in));
+		HIP_TRY(hipEventRecord(h->pipe_ev[b][COPIED_IN], h->pipe_in));
+		HIP_TRY(hipStreamWaitEvent(h->stream, h->pipe_ev[b][COPIED_IN], 0));
+		if (i >= 2 && rows) // ... and its messages have left the slot
+			HIP_TRY(hipStreamWaitEvent(h->stream, h->pipe_ev[b][COPIED_OUT], 0));
+		if ((rc = launch_decode(h, program_id, dout, din, c, h->stream, true))) // timed: polar_hip_last_decode_ms reports the last chunk
+			return rc;
+		HIP_TRY(hipEventRecord(h->pipe_ev[b][DECODED], h->stream));
+		if (rows) {
+			HIP_TRY(hipStreamWaitEvent(h->pipe_out, h->pipe_ev[b][DECODED], 0));
+			HIP_TRY(hipMemcpy2DAsync(message + f0, frames, dout, c, c, rows, hipMemcpyDeviceToHost, h->pipe_out));
+			HIP_TRY(hipEventRecord(h->pipe_ev[b][COPIED_OUT], h->pipe_out));
+		}
+	}
+	HIP_TRY(hipStreamSynchronize(h->pipe_in));
+	HIP_TRY(hipStreamSynchronize(h->stream));
+	HIP_TRY(hipStreamSynchronize(h->pipe_out));
+	return POLAR_OK;
+}
+
 extern "C" int polar_hip_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, int where)
 {
 	int rc = check_decode_args(h, program_id, message, codeword, frames);
@@ -1059,6 +1263,13 @@ extern "C" int polar_hip_decode(polar_hip_handle *h, int program_id, int8_t *mes
 			return rc;
 		HIP_TRY(hipStreamSynchronize(h->stream));
 		return POLAR_OK;
+	}
+	const size_t chunk = pipeline_chunk((size_t)1 << hp.top);
+	if (frames >= 2 * chunk) {
+		if (host_pinned(codeword) && (!hp.rows || host_pinned(message)))
+			return decode_host_pipelined(h, program_id, message, codeword, frames, chunk);
+		if ((chunk << hp.top) <= ((size_t)1 << 30)) // two page-locked slots of a chunk each way: 3 GiB at most
+			return decode_host_staged(h, program_id, message, codeword, frames, chunk);
 	}
 	size_t in_bytes = ((size_t)1 << hp.top) * frames, out_bytes = (size_t)hp.rows * frames;
 	if ((rc = h->stage_in.reserve(in_bytes)) || (rc = h->stage_out.reserve(out_bytes ? out_bytes : 4)))

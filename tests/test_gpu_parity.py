@@ -276,6 +276,38 @@ def test_encoders(session, oracle, golden):
                     assert (cw == oracle.encode(msg, fro, M, sysf)).all(), (M, K, frames, sysf)
 
 
+def test_host_buffers_pipelined(session, oracle, monkeypatch):
+    """polar_hip_decode with several chunks' worth of frames in host buffers takes the chunked
+    paths (copy-in, decode and copy-out overlapped on three streams): same bytes as the oracle,
+    ragged last chunk included, for torch-pinned buffers, the library's own page-locked ones and
+    pageable numpy arrays, with and without message rows."""
+    import torch
+    import polar_amd
+
+    monkeypatch.setenv("POLAR_HIP_HOST_CHUNK", "1024")
+    M, frames = 8, 3 * 1024 + 165
+    N = 1 << M
+    for K in (N // 2, 0):
+        fro = _code(oracle, M, K=K)
+        prog = oracle.compile(fro, M)
+        llr = family_llr("uniform", 31, np.ones((N, frames), np.int8))
+        exp = oracle.decode(llr, prog)
+        t_llr = torch.from_numpy(llr).pin_memory()
+        t_out = torch.zeros((max(K, 1), frames), dtype=torch.int8).pin_memory()
+        polar_amd.PolarDecoder(session)(t_out.numpy()[:K], t_llr.numpy(), prog)
+        assert (t_out.numpy()[:K] == exp).all(), K
+        h_llr, h_out = polar_amd.HostBuffer((N, frames)), polar_amd.HostBuffer((max(K, 1), frames))
+        h_llr.array[:] = llr
+        h_out.array[:] = 0
+        polar_amd.PolarDecoder(session)(h_out.array[:K], h_llr.array, prog)
+        assert (h_out.array[:K] == exp).all(), K
+        h_llr.close()
+        h_out.close()
+        out = np.zeros((max(K, 1), frames), np.int8)  # pageable: gathered into page-locked slots by host threads
+        polar_amd.PolarDecoder(session)(out[:K], llr, prog)
+        assert (out[:K] == exp).all(), K
+
+
 def test_systematic_chain(session, oracle):
     """testbench.cc:129-183 on the device: sysenc -> (noise) -> decode -> re-encode -> gather."""
     import polar_amd
