@@ -70,3 +70,33 @@ def test_static_entry_point_rejections(session, oracle):
     if pid2 >= 0:
         rc = lib.polar_hip_decode_static(session._h, pid2, None, ctypes.c_void_p(llr.data_ptr()), 32, ctypes.c_void_p(0))
         assert rc == -1 and b"static array" in lib.polar_hip_last_error()
+
+
+def test_static_entry_point_in_a_hip_graph(session, oracle):
+    """One of the callers the entry point is for: the launch is captured into a HIP graph (a capture
+    tolerates neither allocation nor synchronisation) and replayed on new LLRs in the same buffers."""
+    import polar_amd
+
+    lib = polar_amd.lib
+    M, frames = 12, 32 * 24
+    N = 1 << M
+    fro, _ = oracle.const0(M, N // 2)
+    prog = oracle.compile(fro, M)
+    pid, rows = session.load_program(prog)
+    llr = torch.zeros((N, frames), dtype=torch.int8, device="cuda")
+    out = torch.zeros((rows, frames), dtype=torch.int8, device="cuda")
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        rc = lib.polar_hip_decode_static(session._h, pid, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(llr.data_ptr()), frames, ctypes.c_void_p(side.cuda_stream))
+        assert rc == 0, lib.polar_hip_last_error()
+    for seed, fam in ((11, "uniform"), (12, "awgn-1")):
+        cw = oracle.encode(pm1_message(seed, N // 2, frames), fro, M, 0)
+        host = family_llr(fam, seed + 1, cw)
+        llr.copy_(torch.from_numpy(host))
+        out.fill_(77)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert (out.cpu().numpy() == oracle.decode(host, prog)).all(), fam
