@@ -359,6 +359,7 @@ struct PackedPass {
 	const int *src_row;    // [N]: message row of a code position, -1 = frozen
 	size_t frames, cols;
 	int level, s0, first, last, wide; // first: PACK_LOAD_*, last: PACK_STORE_*
+	int S, CW;                        // packed_tile_kernel: stages of the pass, columns per tile
 };
 enum { PACK_LOAD_TMP = 0, PACK_LOAD_MESSAGE = 1, PACK_LOAD_REFREEZE = 2 }; // refreeze: tmp, with +1 at the frozen positions (polar_encoder.hh:46-48)
 enum { PACK_STORE_TMP = 0, PACK_STORE_INFO = 1, PACK_STORE_ALL = 2 };      // info rows gathered to [K][...]; all rows as symbols to out[N][frames]
@@ -431,6 +432,111 @@ __global__ void __launch_bounds__(256) packed_transform_kernel(PackedPass a)
 				a.out_sign[(size_t)dst * a.cols + col] = r.neg;
 			if (a.out_eras)
 				a.out_eras[(size_t)dst * a.cols + col] = ~r.nz & valid;
+		}
+	}
+}
+
+// One row of one 32-frame column for the first pass of a transform (a.first) ...
+__device__ __forceinline__ PackedRow packed_load(const PackedPass &a, size_t row, size_t col, size_t f0, u32 valid)
+{
+	if (a.first != PACK_LOAD_TMP) {
+		int src = a.src_row[row];
+		if (src < 0) {
+			PackedRow r = {0u, valid};
+			return r;
+		}
+		if (a.first == PACK_LOAD_MESSAGE)
+			return pack_symbols(a.msg + (size_t)src * a.frames, f0, a.frames, a.wide);
+	}
+	return a.tmp[row * a.cols + col];
+}
+// ... and for the last one (a.last)
+__device__ __forceinline__ void packed_store(const PackedPass &a, size_t row, size_t col, size_t f0, u32 valid, PackedRow r)
+{
+	if (a.last == PACK_STORE_TMP) {
+		a.tmp[row * a.cols + col] = r;
+		return;
+	}
+	if (a.last == PACK_STORE_ALL) {
+		unpack_symbols(a.out + row * a.frames, f0, a.frames, a.wide, r);
+		return;
+	}
+	int dst = a.src_row[row];
+	if (dst < 0)
+		return;
+	if (a.out)
+		unpack_symbols(a.out + (size_t)dst * a.frames, f0, a.frames, a.wide, r);
+	if (a.out_sign)
+		a.out_sign[(size_t)dst * a.cols + col] = r.neg;
+	if (a.out_eras)
+		a.out_eras[(size_t)dst * a.cols + col] = ~r.nz & valid;
+}
+
+// S = 4..10 stages per pass: a workgroup owns a tile of 2^S rows {row_base + (r << s0)} x CW
+// columns (2^S * CW <= 4096 packed rows, 32 KiB of LDS), a thread 16 rows of one column in
+// registers. The stages are done four at a time on the rows that differ in those four bits of r;
+// between such phases the tile goes through LDS and the threads regroup. The last phase takes the
+// top four bits and skips the stages already done. Global accesses are CW * 8 bytes (CW * 32 for
+// symbols) contiguous per row.
+enum { TILE_ITEMS = 4096, TILE_ROWS = 16 };
+__global__ void __launch_bounds__(TILE_ITEMS / TILE_ROWS) packed_tile_kernel(PackedPass a)
+{
+	__shared__ u32 tile_neg[TILE_ITEMS], tile_nz[TILE_ITEMS];
+	const int S = a.S, CW = a.CW;
+	const int c = (int)threadIdx.x % CW, g = (int)threadIdx.x / CW; // g: the S - 4 bits of r a phase does not touch
+	const size_t col_tiles = (a.cols + CW - 1) / CW;
+	const size_t col = (blockIdx.x % col_tiles) * CW + c, j = blockIdx.x / col_tiles; // j enumerates rows with bits [s0, s0+S) clear
+	const bool live = col < a.cols;
+	const size_t row_base = ((j >> a.s0) << (a.s0 + S)) | (j & (((size_t)1 << a.s0) - 1));
+	const size_t f0 = 32 * col;
+	const u32 valid = !live ? 0u : a.frames - f0 >= 32 ? ~0u : (1u << (a.frames - f0)) - 1u;
+	const int phases = (S + 3) / 4;
+	u32 neg[TILE_ROWS], nz[TILE_ROWS];
+	for (int p = 0; p < phases; ++p) {
+		const int done = 4 * p;                            // stages below this bit are finished
+		const int lo = p == phases - 1 ? S - 4 : done;     // this phase's rows differ in bits [lo, lo+4)
+		const int r0 = ((g >> lo) << (lo + 4)) | (g & ((1 << lo) - 1));
+#pragma unroll
+		for (int k = 0; k < TILE_ROWS; ++k) {
+			const int r = r0 | (k << lo);
+			if (p == 0) {
+				PackedRow x = {0u, 0u};
+				if (live)
+					x = packed_load(a, row_base + ((size_t)r << a.s0), col, f0, valid);
+				neg[k] = x.neg;
+				nz[k] = x.nz;
+			} else {
+				neg[k] = tile_neg[r * CW + c];
+				nz[k] = tile_nz[r * CW + c];
+			}
+		}
+#pragma unroll
+		for (int t = 0; t < 4; ++t)
+			if (lo + t >= done) {
+#pragma unroll
+				for (int k = 0; k < TILE_ROWS; ++k)
+					if (!(k & (1 << t))) { // qmul(a, b): sign xor, zero if either is zero
+						neg[k] ^= neg[k + (1 << t)];
+						nz[k] &= nz[k + (1 << t)];
+					}
+			}
+		if (p == phases - 1) {
+#pragma unroll
+			for (int k = 0; k < TILE_ROWS; ++k) {
+				PackedRow x = {neg[k] & nz[k], nz[k]};
+				if (live)
+					packed_store(a, row_base + ((size_t)(r0 | (k << lo)) << a.s0), col, f0, valid, x);
+			}
+		} else {
+			if (p)
+				__syncthreads(); // every thread has read its rows of the previous phase
+#pragma unroll
+			for (int k = 0; k < TILE_ROWS; ++k) {
+				const int r = r0 | (k << lo);
+				tile_neg[r * CW + c] = neg[k];
+				tile_nz[r * CW + c] = nz[k];
+			}
+			__syncthreads();
 		}
 	}
 }
@@ -1551,11 +1657,39 @@ static int pack_cmax()
 	return c;
 }
 static size_t packed_cols(size_t frames) { return (frames + 31) / 32; }
-static size_t packed_tmp_bytes(int level, size_t frames) { return level > pack_cmax() ? ((size_t)1 << level) * packed_cols(frames) * sizeof(PackedRow) : 0; }
+static size_t packed_tmp_bytes(int level, size_t frames) { return level > pack_cmax() ? ((size_t)1 << level) * packed_cols(frames) * sizeof(PackedRow) : 0; } // also covers the tile passes (one pass up to level 10)
 
 // one transform over packed rows: `load` for the first pass, `store` for the last one
 static int packed_transform(polar_hip_handle *h, PackedPass a, int level, int load, int store, uint8_t *out, u32 *out_sign, u32 *out_eras, const char *who)
 {
+	static const bool tiles = !getenv("POLAR_HIP_PACK_C"); // experiments: the register-only passes for every size
+	if (tiles && level >= 6) { // tile passes through LDS: one pass up to 2^10 rows (4 columns = 128 bytes of symbols per row), then at most 8 stages per pass
+		static const int single = getenv("POLAR_HIP_TILE_SINGLE") ? atoi(getenv("POLAR_HIP_TILE_SINGLE")) : 10; // experiments only
+		static const int smax = getenv("POLAR_HIP_TILE_S") ? atoi(getenv("POLAR_HIP_TILE_S")) : 8;
+		const int passes = level <= single ? 1 : (level + smax - 1) / smax;
+		for (int s0 = 0, pass = 0; s0 < level; ++pass) {
+			const int S = (level - s0 + (passes - pass) - 1) / (passes - pass);
+			const bool last = s0 + S >= level;
+			int CW = TILE_ITEMS >> S > 64 ? 64 : TILE_ITEMS >> S;
+			while (CW > 1 && (size_t)CW / 2 >= a.cols)
+				CW /= 2;
+			a.s0 = s0;
+			a.S = S;
+			a.CW = CW;
+			a.first = s0 == 0 ? load : PACK_LOAD_TMP;
+			a.last = last ? store : PACK_STORE_TMP;
+			a.out = last ? out : nullptr;
+			a.out_sign = last ? out_sign : nullptr;
+			a.out_eras = last ? out_eras : nullptr;
+			size_t blocks = (((size_t)1 << level) >> S) * ((a.cols + CW - 1) / CW);
+			if (blocks > 0x7FFFFFFFu)
+				return fail(POLAR_E_ARG, std::string(who) + ": too many frames for one call");
+			hipLaunchKernelGGL(packed_tile_kernel, dim3((unsigned)blocks), dim3((unsigned)((CW << S) / TILE_ROWS)), 0, h->stream, a);
+			HIP_TRY(hipGetLastError());
+			s0 += S;
+		}
+		return POLAR_OK;
+	}
 	const int passes = (level + pack_cmax() - 1) / pack_cmax();
 	for (int s0 = 0, pass = 0; s0 < level; ++pass) {
 		int c = (level - s0 + (passes - pass) - 1) / (passes - pass); // what is left, spread over the passes left
