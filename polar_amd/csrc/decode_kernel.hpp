@@ -52,7 +52,41 @@ __global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
 		if (grp >= a.groups)
 			continue;
 		size_t g0 = (size_t)grp * (4 * Q);
-		g.in = InVec<Q>{a.cw + g0, a.stride};
+		g.in = typename G::In{a.cw + g0, a.stride};
+		g.out = OutRows<Q>{a.msg + g0, a.stride};
+		g.run((prog_ptr)a.prog);
+	}
+}
+
+// Team form: a workgroup of TEAM_WAVES wavefronts, wavefront w of block b takes the groups
+// TEAM_WAVES * slot + w (the host pads the batch to whole teams), arena b * TEAM_WAVES + w.
+enum { TEAM_WAVES = 4 };
+template <int Q, int RL>
+__global__ void __launch_bounds__(64 * TEAM_WAVES, 2) sc_decode_team_kernel(DecodeArgs a)
+{
+	typedef Group<Q, RL, true> G;
+	__shared__ __attribute__((aligned(16))) u32 lds[TEAM_WAVES * G::LDS_DWORDS];
+	const u32 nb = gridDim.x, b = blockIdx.x, w = threadIdx.x >> 6;
+	const u32 slot = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
+	u32 *arena = a.scratch ? a.scratch + ((size_t)b * TEAM_WAVES + w) * a.block_dwords : nullptr;
+	const size_t plane = ((size_t)Q << a.top) / 8;
+	G g;
+	g.sl = (lds_u32 *)lds + w * G::LDS_DWORDS;
+	g.hls = g.sl + G::LDS_SOFT;
+	g.hlz = g.hls + G::LDS_PLANE;
+	g.sg = arena;
+	g.hgs = arena ? arena + ((size_t)Q << a.top) : nullptr;
+	g.hgz = arena ? g.hgs + plane : nullptr;
+	g.top = a.top;
+#ifdef POLAR_PROFILE
+	g.prof = a.prof;
+#endif
+	for (u32 base = 0; base < a.groups; base += TEAM_WAVES * nb) {
+		u32 grp = base + TEAM_WAVES * slot + w;
+		if (base + TEAM_WAVES * slot >= a.groups) // whole teams only (a.groups is a multiple of TEAM_WAVES)
+			continue;
+		size_t g0 = (size_t)grp * (4 * Q);
+		g.in = typename G::In{a.cw + g0, a.stride};
 		g.out = OutRows<Q>{a.msg + g0, a.stride};
 		g.run((prog_ptr)a.prog);
 	}
@@ -65,10 +99,11 @@ struct KernelVariant {
 	decode_kernel_t fn;
 	size_t lds_bytes;
 	int chain_depth;
+	int team; // wavefronts per workgroup: 1, or TEAM_WAVES for the team form
 };
 
-enum { VARIANT_GROUPS = 8 };
+enum { VARIANT_GROUPS = 9 };
 // the variants compiled into group g (variants.hip with -DVARIANT_GROUP=g)
 #define DECLARE_GROUP(g) const KernelVariant *polar_variant_group_##g(int *count);
-DECLARE_GROUP(0) DECLARE_GROUP(1) DECLARE_GROUP(2) DECLARE_GROUP(3) DECLARE_GROUP(4) DECLARE_GROUP(5) DECLARE_GROUP(6) DECLARE_GROUP(7)
+DECLARE_GROUP(0) DECLARE_GROUP(1) DECLARE_GROUP(2) DECLARE_GROUP(3) DECLARE_GROUP(4) DECLARE_GROUP(5) DECLARE_GROUP(6) DECLARE_GROUP(7) DECLARE_GROUP(8)
 #undef DECLARE_GROUP

@@ -53,7 +53,7 @@ struct VariantTable {
 	{
 		typedef const KernelVariant *(*group_fn)(int *);
 		static const group_fn groups[VARIANT_GROUPS] = {polar_variant_group_0, polar_variant_group_1, polar_variant_group_2, polar_variant_group_3,
-			polar_variant_group_4, polar_variant_group_5, polar_variant_group_6, polar_variant_group_7};
+			polar_variant_group_4, polar_variant_group_5, polar_variant_group_6, polar_variant_group_7, polar_variant_group_8};
 		for (group_fn g : groups) {
 			int n = 0;
 			const KernelVariant *t = g(&n);
@@ -67,10 +67,10 @@ static const std::vector<KernelVariant> &variants()
 	return t.v;
 }
 
-static const KernelVariant *find_variant(int q, int rl)
+static const KernelVariant *find_variant(int q, int rl, int team = 1)
 {
 	for (const KernelVariant &v : variants())
-		if (v.q == q && v.rl == rl)
+		if (v.q == q && v.rl == rl && v.team == team)
 			return &v;
 	return nullptr;
 }
@@ -1018,8 +1018,11 @@ extern "C" int polar_hip_code(polar_hip_handle *h, int level, int K, long double
 
 static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, size_t frames, ScratchBudget &budget)
 {
-	if (h->cfg_frames_per_wave)
-		return find_variant(h->cfg_frames_per_wave / 4, h->cfg_lds_level);
+	static const bool teams = getenv("POLAR_HIP_TEAM") != nullptr; // experiments only
+	if (h->cfg_frames_per_wave) {
+		const KernelVariant *t = teams ? find_variant(h->cfg_frames_per_wave / 4, h->cfg_lds_level, TEAM_WAVES) : nullptr;
+		return t ? t : find_variant(h->cfg_frames_per_wave / 4, h->cfg_lds_level);
+	}
 	// Measured (tools/gpu_sweep_pick.sh): a wavefront walks the program in about the same
 	// time whatever its width, so the widest group wins as soon as every resident wavefront has
 	// one; groups of at most 32 frames already pay off when half of the wavefronts have one.
@@ -1050,14 +1053,15 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	int rc;
 	if ((rc = upload_shape(lp, v))) // first use with this wavefront shape: fuse and upload
 		return rc;
-	const size_t fpw = 4 * (size_t)v->q, n = (size_t)1 << lp.host.top, rows = lp.host.rows;
-	size_t groups = (frames + fpw - 1) / fpw;
+	// a workgroup takes `team` neighbouring groups at a time (1, or TEAM_WAVES in the team form)
+	const size_t team = (size_t)v->team, fpw = 4 * (size_t)v->q * team, n = (size_t)1 << lp.host.top, rows = lp.host.rows;
+	const size_t units = (frames + fpw - 1) / fpw, groups = units * team;
 	if (groups > 0x7FFFFFFFu)
 		return fail(POLAR_E_ARG, "too many frames for one call");
 	h->timed = false;
 	if (!groups)
 		return POLAR_OK;
-	const size_t padded = groups * fpw;
+	const size_t padded = units * fpw;
 	const bool direct = padded == frames && (uintptr_t)codeword % 16 == 0 && (uintptr_t)message % 16 == 0;
 	const uint8_t *cw = (const uint8_t *)codeword;
 	uint8_t *msg = (uint8_t *)message;
@@ -1072,7 +1076,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	int per_cu = 0;
 	auto occ = h->occupancy.find((const void *)v->fn);
 	if (occ == h->occupancy.end()) {
-		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->fn, 64, 0));
+		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->fn, 64 * v->team, 0));
 		h->occupancy[(const void *)v->fn] = per_cu;
 	} else {
 		per_cu = occ->second;
@@ -1080,14 +1084,14 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	if (per_cu < 1)
 		return fail(POLAR_E_HIP, "decode kernel does not fit on a CU");
 	size_t blocks = (size_t)per_cu * h->cus;
-	if (h->cfg_max_waves && (size_t)h->cfg_max_waves < blocks)
-		blocks = h->cfg_max_waves;
+	if (h->cfg_max_waves && (size_t)h->cfg_max_waves / team < blocks)
+		blocks = (size_t)h->cfg_max_waves / team ? (size_t)h->cfg_max_waves / team : 1;
 	size_t block_dwords = 0, max_blocks = ~(size_t)0 >> 8;
 	if (lp.host.top > v->rl) { // LLR levels above the LDS levels and the partial-sum planes live in scratch
 		size_t soft = (size_t)v->q << lp.host.top;
 		block_dwords = soft + 2 * (soft / 8);
-		if (!budget.fits(blocks * block_dwords * sizeof(u32))) { // fewer resident wavefronts, more sweeps
-			max_blocks = budget.limit() / (block_dwords * sizeof(u32));
+		if (!budget.fits(blocks * team * block_dwords * sizeof(u32))) { // fewer resident wavefronts, more sweeps
+			max_blocks = budget.limit() / (team * block_dwords * sizeof(u32));
 			if (max_blocks < 1)
 				return fail(POLAR_E_NOMEM, "not enough device memory for one wavefront's scratch arena");
 			if (blocks > max_blocks)
@@ -1095,12 +1099,12 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 		}
 	}
 	// every wavefront walks the same number of groups: no idle tail behind a last partial sweep
-	size_t sweeps = (groups + blocks - 1) / blocks;
-	blocks = (groups + sweeps - 1) / sweeps;
+	size_t sweeps = (units + blocks - 1) / blocks;
+	blocks = (units + sweeps - 1) / sweeps;
 	if (blocks >= 8 && blocks % 8) // multiple of 8 for the XCD-aware group order
 		blocks = blocks + 8 - blocks % 8 <= max_blocks ? blocks + 8 - blocks % 8 : blocks - blocks % 8;
 	if (getenv("POLAR_HIP_DEBUG"))
-		fprintf(stderr, "polar_hip: decode Q=%d RL=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d\n", v->q, v->rl, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct);
+		fprintf(stderr, "polar_hip: decode Q=%d RL=%d team=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d\n", v->q, v->rl, v->team, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct);
 	DecodeArgs a;
 	a.prog = lp.dev[shape];
 	a.cw = cw;
@@ -1112,7 +1116,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	a.block_dwords = 0;
 	if (block_dwords) {
 		a.block_dwords = block_dwords;
-		if ((rc = h->scratch.reserve(blocks * block_dwords * sizeof(u32))))
+		if ((rc = h->scratch.reserve(blocks * team * block_dwords * sizeof(u32))))
 			return rc;
 		a.scratch = (u32 *)h->scratch.p;
 	}
@@ -1126,7 +1130,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 #endif
 	if (timed)
 		HIP_TRY(hipEventRecord(h->ev0, stream));
-	hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64), 0, stream, a);
+	hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64 * (unsigned)team), 0, stream, a);
 	HIP_TRY(hipGetLastError());
 #ifdef POLAR_PROFILE
 	{

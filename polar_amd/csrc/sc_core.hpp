@@ -96,6 +96,7 @@ PDEV u32 perm(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, se
 // of one lane are visible to the others: a single wavefront executes its DS / VMEM
 // instructions in order, so only the compiler has to be kept from reordering.
 PDEV void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+PDEV void team_sync() { __builtin_amdgcn_s_barrier(); } // no data is exchanged: pace only
 // nonzero in any lane (wave-uniform result); the host emulation ORs lane after lane instead
 PDEV u32 wave_any(u32 v) { return __builtin_amdgcn_ballot_w64(v != 0) != 0; }
 #endif
@@ -239,7 +240,9 @@ struct LVec { // linear dword array in LDS
 // the caller's codeword buffer: row i of the group starts at p + i*stride (bytes). The host
 // guarantees dword-aligned rows and whole groups (ragged batches are staged through a padded
 // copy, polar_hip.hip), so a row segment of the group is Q aligned dwords.
-template <int Q> struct InVec {
+// NT = false (team kernels): default-policy loads, so that a line fetched for one wavefront of a
+// team still serves the neighbouring groups' segments of it.
+template <int Q, bool NT = true> struct InVec {
 	const uint8_t *p; // first byte of the group's frames in row 0
 	size_t stride;    // bytes per row
 	PDEV u32 ld(int t) const
@@ -252,10 +255,10 @@ template <int Q> struct InVec {
 		if (Q % 4 == 0) { // four consecutive quads of one row: rows are 16-byte aligned then
 			int i = t / Q, q = t % Q;
 #if !defined(POLAR_EMU) && !defined(POLAR_NO_NT)
-			return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + (size_t)i * stride + 4 * q));
-#else
-			return *reinterpret_cast<const u32x4 *>(p + (size_t)i * stride + 4 * q);
+			if (NT)
+				return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + (size_t)i * stride + 4 * q));
 #endif
+			return *reinterpret_cast<const u32x4 *>(p + (size_t)i * stride + 4 * q);
 		}
 		u32x4 v;
 		v.x = ld(t); v.y = ld(t + 1); v.z = ld(t + 2); v.w = ld(t + 3);
@@ -328,8 +331,12 @@ PDEV void ew_pairs(const A &a, const D &d, int n, Fn fn)
 }
 
 // One group's decoder state.
-template <int Q, int RL>
+// TEAM: four wavefronts of one workgroup decode four neighbouring groups side by side (each with
+// its own LDS slice and arena) and meet at a barrier before every pass over the input rows, so
+// that they read the 128-byte lines their row segments share at the same time.
+template <int Q, int RL, bool TEAM = false>
 struct Group {
+	typedef InVec<Q, !TEAM> In;
 	static_assert(RL >= 4, "nodes that share a partial-sum octet must live in LDS");
 	static const int W = 1 << (RL + 1); // elements of the LDS partial-sum window
 	static const int LDS_SOFT = Q << (RL + 1), LDS_PLANE = (W / 8) * Q;
@@ -341,7 +348,7 @@ struct Group {
 	lds_u32 *hls, *hlz; // LDS partial-sum planes (sign, zero), LDS_PLANE dwords each, index by position mod W
 	u32 *sg;            // scratch soft arena, Q << top dwords
 	u32 *hgs, *hgz;     // scratch partial-sum planes, (Q << top) / 8 dwords each
-	InVec<Q> in;
+	In in;
 	OutRows<Q> out;
 	int top;
 	// Zero planes in scratch are only written for nodes that hold an erasure (decision 0), which
@@ -450,8 +457,8 @@ struct Group {
 	static PDEV u32x4 ldE(const LVec &v, int t, u32x4) { return v.ld4(t); }
 	static PDEV u32 ldE(const GVec &v, int t, u32) { return v.ld(t); }
 	static PDEV u32x4 ldE(const GVec &v, int t, u32x4) { return v.ld4(t); }
-	static PDEV u32 ldE(const InVec<Q> &v, int t, u32) { return v.ld(t); }
-	static PDEV u32x4 ldE(const InVec<Q> &v, int t, u32x4) { return v.ld4(t); }
+	static PDEV u32 ldE(const In &v, int t, u32) { return v.ld(t); }
+	static PDEV u32x4 ldE(const In &v, int t, u32x4) { return v.ld4(t); }
 	static PDEV u32x4 ldE(const AnySrc &v, int t, u32x4) { return v.ld4(t); }
 	PDEV void stE(int level, int t, u32 v) const
 	{
@@ -1491,6 +1498,8 @@ struct Group {
 				atomicAdd(&prof[slot + 1], 1ull);
 			}
 #else
+			if (TEAM && lvl == top)
+				team_sync();
 			node(op, lvl, hrd, row, pad);
 #endif
 

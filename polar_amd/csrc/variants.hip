@@ -4,7 +4,8 @@
 //   ~40 KB (3 per CU): (16,10) (16,8).
 #include "decode_kernel.hpp"
 
-#define VARIANT(q, rl) {q, rl, sc_decode_kernel<q, rl>, sizeof(u32) * (size_t)Group<q, rl>::LDS_DWORDS, Group<q, rl>::CHAIN_DEPTH}
+#define VARIANT(q, rl) {q, rl, sc_decode_kernel<q, rl>, sizeof(u32) * (size_t)Group<q, rl>::LDS_DWORDS, Group<q, rl>::CHAIN_DEPTH, 1}
+#define TEAM_VARIANT(q, rl) {q, rl, sc_decode_team_kernel<q, rl>, sizeof(u32) * (size_t)Group<q, rl>::LDS_DWORDS * TEAM_WAVES, Group<q, rl>::CHAIN_DEPTH, TEAM_WAVES}
 static const KernelVariant table[] = {
 #if VARIANT_GROUP == 0
 	VARIANT(32, 6), VARIANT(1, 11),
@@ -22,9 +23,12 @@ static const KernelVariant table[] = {
 	VARIANT(8, 7), VARIANT(16, 7),
 #elif VARIANT_GROUP == 7
 	VARIANT(4, 10),
+#elif VARIANT_GROUP == 8
+	TEAM_VARIANT(8, 8), TEAM_VARIANT(16, 7),
 #endif
 };
 #undef VARIANT
+#undef TEAM_VARIANT
 
 #define GROUP_FN2(g) polar_variant_group_##g
 #define GROUP_FN(g) GROUP_FN2(g)

@@ -54,6 +54,7 @@ static inline u32 perm(u32 s0, u32 s1, u32 sel)
 	return r;
 }
 static inline void wave_sync() {}
+static inline void team_sync() {}
 static inline u32 wave_any(u32 v) { return v != 0; }
 }
 
