@@ -88,6 +88,10 @@ void polar_hip_destroy(polar_hip_handle *h);
  * and the number of resident wavefronts (0 = fill the device). frames_per_wave = 0 restores the
  * default: chosen per call from the batch size, the code size and the free device memory. */
 int polar_hip_configure(polar_hip_handle *h, int frames_per_wave, int lds_level, int max_waves);
+/* The same with the team size: wavefronts per workgroup that decode neighbouring groups side by
+ * side and pace their passes over the input rows (1 = one wavefront per workgroup, what
+ * polar_hip_configure selects; 4 is compiled for (32, 8) and (64, 7)). */
+int polar_hip_configure_team(polar_hip_handle *h, int frames_per_wave, int lds_level, int team, int max_waves);
 
 /* Stream the synchronous entry points enqueue on: use_callers != 0 selects `stream` (a
  * hipStream_t, NULL = the null stream), 0 restores the handle's private stream. Work already

@@ -166,8 +166,8 @@ class Session:
                     self._stream = st
                 return
 
-    def configure(self, frames_per_wave=0, lds_level=0, max_waves=0):
-        _check(lib.polar_hip_configure(self._h, frames_per_wave, lds_level, max_waves), "polar_hip_configure")
+    def configure(self, frames_per_wave=0, lds_level=0, max_waves=0, team=1):
+        _check(lib.polar_hip_configure_team(self._h, frames_per_wave, lds_level, team, max_waves), "polar_hip_configure")
 
     def load_program(self, program):
         program = np.ascontiguousarray(program, np.uint8)

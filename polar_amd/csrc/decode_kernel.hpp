@@ -60,8 +60,9 @@ __global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
 
 // Team form: a workgroup of TEAM_WAVES wavefronts, wavefront w of block b takes the groups
 // TEAM_WAVES * slot + w (the host pads the batch to whole teams), arena b * TEAM_WAVES + w.
-enum { TEAM_WAVES = 4 };
-template <int Q, int RL>
+// Two wavefronts per SIMD are asked for outright: left alone the compiler budgets the registers
+// for one (253 + 4 accumulation registers) and halves the occupancy.
+template <int Q, int RL, int TEAM_WAVES>
 __global__ void __launch_bounds__(64 * TEAM_WAVES, 2) sc_decode_team_kernel(DecodeArgs a)
 {
 	typedef Group<Q, RL, true> G;
@@ -99,7 +100,7 @@ struct KernelVariant {
 	decode_kernel_t fn;
 	size_t lds_bytes;
 	int chain_depth;
-	int team; // wavefronts per workgroup: 1, or TEAM_WAVES for the team form
+	int team; // wavefronts per workgroup: 1, or the team size of the team form
 };
 
 enum { VARIANT_GROUPS = 9 };

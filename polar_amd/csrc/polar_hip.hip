@@ -705,7 +705,7 @@ struct polar_hip_handle {
 	DeviceBuffer scratch, stage_in, stage_out, enc_tmp, tables, counters, pad_in, pad_out;
 	DeviceBuffer sim_cw, sim_llr, sim_msg, sim_dec; // polar_hip_simulate's chunk
 	std::vector<uint8_t> frozen_cache; // frozen set the device tables were built from
-	int cfg_frames_per_wave = 0, cfg_lds_level = 0, cfg_max_waves = 0;
+	int cfg_frames_per_wave = 0, cfg_lds_level = 0, cfg_team = 1, cfg_max_waves = 0;
 };
 
 static int use_device(polar_hip_handle *h)
@@ -892,23 +892,26 @@ extern "C" void polar_hip_destroy(polar_hip_handle *h)
 	delete h;
 }
 
-extern "C" int polar_hip_configure(polar_hip_handle *h, int frames_per_wave, int lds_level, int max_waves)
+extern "C" int polar_hip_configure_team(polar_hip_handle *h, int frames_per_wave, int lds_level, int team, int max_waves)
 {
 	if (!h)
 		return fail(POLAR_E_ARG, "polar_hip_configure: null handle");
 	if (frames_per_wave || lds_level) {
-		bool found = false;
-		for (const KernelVariant &v : variants())
-			found |= 4 * v.q == frames_per_wave && v.rl == lds_level;
-		if (!found)
-			return fail(POLAR_E_ARG, "polar_hip_configure: no kernel built for this (frames_per_wave, lds_level)");
+		if (frames_per_wave % 4 || !find_variant(frames_per_wave / 4, lds_level, team))
+			return fail(POLAR_E_ARG, "polar_hip_configure: no kernel built for this (frames_per_wave, lds_level, team)");
 	}
 	if (max_waves < 0)
 		return fail(POLAR_E_ARG, "polar_hip_configure: negative max_waves");
 	h->cfg_frames_per_wave = frames_per_wave;
 	h->cfg_lds_level = lds_level;
+	h->cfg_team = team;
 	h->cfg_max_waves = max_waves;
 	return POLAR_OK;
+}
+
+extern "C" int polar_hip_configure(polar_hip_handle *h, int frames_per_wave, int lds_level, int max_waves)
+{
+	return polar_hip_configure_team(h, frames_per_wave, lds_level, 1, max_waves);
 }
 
 extern "C" int polar_hip_set_stream(polar_hip_handle *h, void *stream, int use_callers)
@@ -1018,23 +1021,22 @@ extern "C" int polar_hip_code(polar_hip_handle *h, int level, int K, long double
 
 static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, size_t frames, ScratchBudget &budget)
 {
-	static const bool teams = getenv("POLAR_HIP_TEAM") != nullptr; // experiments only
-	if (h->cfg_frames_per_wave) {
-		const KernelVariant *t = teams ? find_variant(h->cfg_frames_per_wave / 4, h->cfg_lds_level, TEAM_WAVES) : nullptr;
-		return t ? t : find_variant(h->cfg_frames_per_wave / 4, h->cfg_lds_level);
-	}
-	// Measured (tools/gpu_sweep_pick.sh): a wavefront walks the program in about the same
-	// time whatever its width, so the widest group wins as soon as every resident wavefront has
-	// one; groups of at most 32 frames already pay off when half of the wavefronts have one.
+	if (h->cfg_frames_per_wave)
+		return find_variant(h->cfg_frames_per_wave / 4, h->cfg_lds_level, h->cfg_team);
+	// Measured (tools/gpu_sweep_pick.sh, tools/gpu_team*.sh): a wavefront walks
+	// the program in about the same time whatever its width, so the widest group wins as soon as
+	// every resident wavefront has one -- two for 128 frames, whose one-sweep batches the 64-frame
+	// teams decode faster; groups of at most 32 frames already pay off when half of the wavefronts
+	// have one. Groups of 32 and 64 frames go in teams of four (whole 128-byte input lines).
 	const size_t resident = (size_t)8 * h->cus;
-	static const int family[][2] = {{32, 6}, {16, 7}, {8, 8}, {4, 9}, {2, 10}, {1, 11}};
+	static const int family[][3] = {{32, 6, 1}, {16, 7, 4}, {8, 8, 4}, {4, 9, 1}, {2, 10, 1}, {1, 11, 1}};
 	for (const auto &f : family) {
 		size_t groups = (frames + 4 * f[0] - 1) / (4 * f[0]);
-		if (f[0] > 1 && groups < (f[0] <= 8 ? resident / 2 : resident))
+		if (f[0] > 1 && groups < (f[0] == 32 ? 2 * resident : f[0] <= 8 ? resident / 2 : resident))
 			continue;
 		if (f[0] > 1 && top > f[1] && !budget.fits(resident * scratch_bytes_per_wave(f[0], top)))
 			continue;
-		return find_variant(f[0], f[1]);
+		return find_variant(f[0], f[1], f[2]);
 	}
 	return nullptr;
 }

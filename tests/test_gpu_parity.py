@@ -61,10 +61,11 @@ def test_decoder_golden_digests(session, oracle, golden, M):
         assert "%016x" % fnv1a64(out) == k["out_fnv"], (M, k["family"])
 
 
-@pytest.mark.parametrize("fpw,rl", [(4, 11), (8, 10), (16, 9), (32, 8), (64, 7), (16, 10), (16, 8), (64, 6), (128, 6), (128, 5), (256, 5), (256, 4)])
-def test_decoder_vs_oracle_all_variants(session, oracle, fpw, rl):
-    """Every built kernel variant, ragged frame counts (tail groups, unaligned rows)."""
-    session.configure(fpw, rl, 0)
+@pytest.mark.parametrize("fpw,rl,team", [(4, 11, 1), (8, 10, 1), (16, 9, 1), (32, 8, 1), (64, 7, 1), (16, 10, 1), (16, 8, 1), (64, 6, 1), (128, 6, 1), (128, 5, 1), (256, 5, 1),
+                                         (256, 4, 1), (32, 8, 4), (64, 7, 4)])
+def test_decoder_vs_oracle_all_variants(session, oracle, fpw, rl, team):
+    """Every built kernel variant, ragged frame counts (tail groups, unaligned rows, part teams)."""
+    session.configure(fpw, rl, 0, team)
     try:
         for M, frames in ((1, 5), (2, 64), (3, 7), (5, 130), (8, 257), (10, 96), (11, 33), (13, 40)):
             N = 1 << M
@@ -82,8 +83,8 @@ def test_decoder_vs_oracle_all_variants(session, oracle, fpw, rl):
         session.configure(0, 0, 0)
 
 
-@pytest.mark.parametrize("fpw,rl", [(128, 6), (128, 5), (64, 7), (256, 5)])
-def test_wide_variants_full_size_digest(session, oracle, golden, fpw, rl):
+@pytest.mark.parametrize("fpw,rl,team", [(128, 6, 1), (128, 5, 1), (64, 7, 1), (256, 5, 1), (64, 7, 4), (32, 8, 4)])
+def test_wide_variants_full_size_digest(session, oracle, golden, fpw, rl, team):
     """The variants the default picks for big batches, on the reference's N = 2^16 digests: the
     32 golden frames are embedded in a batch wide enough for whole 128/256-frame groups."""
     meta, _ = golden
@@ -91,24 +92,26 @@ def test_wide_variants_full_size_digest(session, oracle, golden, fpw, rl):
     N = 1 << M
     fro = _code(oracle, M)
     prog = oracle.compile(fro, M)
-    session.configure(fpw, rl, 0)
+    session.configure(fpw, rl, 0, team)
     try:
         for k in [k for k in meta["decoder_digests"] if k["M"] == M]:
             cw = oracle.encode(pm1_message(k["msg_seed"], N // 2, k["frames"]), fro, M, 1)
             llr = family_llr(k["family"], k["llr_seed"], cw)
-            wide = np.ascontiguousarray(np.tile(llr, (1, 9))[:, :fpw + 32 + 5])  # ragged: one full group + a tail
+            wide = np.ascontiguousarray(np.tile(llr, (1, 20))[:, :fpw * team + 32 + 5])  # ragged: one full group (team) + a tail
             out = _decode(session, wide, prog, N // 2)
             for a in range(0, wide.shape[1] - 31, 32):
-                assert "%016x" % fnv1a64(np.ascontiguousarray(out[:, a:a + 32])) == k["out_fnv"], (fpw, rl, k["family"], a)
+                assert "%016x" % fnv1a64(np.ascontiguousarray(out[:, a:a + 32])) == k["out_fnv"], (fpw, rl, team, k["family"], a)
     finally:
         session.configure(0, 0, 0)
 
 
-@pytest.mark.parametrize("M,frames", [(16, 1 << 18), (16, (1 << 18) + 128 * 300 + 52), (20, 4096 + 96)])
+@pytest.mark.parametrize("M,frames", [(16, 1 << 19), (16, (1 << 18) + 128 * 300 + 52), (16, 40000 + 21), (20, 4096 + 96)])
 def test_bench_grid_parity(session, oracle, golden, M, frames):
     """The exact path bench.py times: default variant pick on a batch that fills every resident
-    wavefront for several sweeps (N = 2^16: (128, 6), >= 2048 persistent workgroups, the XCD-aware
-    group order, the multi-GiB scratch arena), and a size that is not a multiple of the sweep. The
+    wavefront for several sweeps (N = 2^16, 2^19 frames: (128, 6), >= 2048 persistent workgroups,
+    the XCD-aware group order, the multi-GiB scratch arena), and the team kernels the default pick
+    takes below that ((64, 7) and (32, 8) in teams of four) on sizes that are not a multiple of
+    the sweep or of a team. The
     32 golden frames of the reference are tiled over the batch on the device: every 32-frame block
     of the output must equal block 0, and block 0 must hash to the reference's digest."""
     import polar_amd
@@ -139,11 +142,11 @@ def test_bench_grid_parity(session, oracle, golden, M, frames):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("fpw,rl,waves", [(128, 6, 16), (128, 6, 8), (4, 11, 8), (32, 8, 24)])
-def test_persistent_sweeps_vs_oracle(session, oracle, fpw, rl, waves):
+@pytest.mark.parametrize("fpw,rl,waves,team", [(128, 6, 16, 1), (128, 6, 8, 1), (4, 11, 8, 1), (32, 8, 24, 1), (32, 8, 24, 4), (64, 7, 8, 4)])
+def test_persistent_sweeps_vs_oracle(session, oracle, fpw, rl, waves, team):
     """Few resident wavefronts, many groups each: the `base += nb` sweep loop with stale LDS /
     scratch planes and the erasure flags of the previous group, on inputs full of erasures."""
-    session.configure(fpw, rl, waves)
+    session.configure(fpw, rl, waves, team)
     try:
         for M, frames in ((8, 40 * fpw), (10, 37 * fpw + 5), (12, 5 * waves * fpw + 3)):
             N = 1 << M
@@ -152,7 +155,7 @@ def test_persistent_sweeps_vs_oracle(session, oracle, fpw, rl, waves):
             cw = oracle.encode(pm1_message(M, N // 2, frames), fro, M, 0)
             for fam in ("small", "uniform"):
                 llr = family_llr(fam, 3 * M + frames, cw)
-                assert (_decode(session, llr, prog, N // 2) == oracle.decode(llr, prog)).all(), (fpw, rl, waves, M, fam)
+                assert (_decode(session, llr, prog, N // 2) == oracle.decode(llr, prog)).all(), (fpw, rl, waves, team, M, fam)
     finally:
         session.configure(0, 0, 0)
 

@@ -1,5 +1,7 @@
 #!/bin/bash
+# config D again (the default pick is now the team form of (32, 8)): profile + bench line
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-POLAR_HIP_LIB=$PWD/polar_amd/libpolar_hip_prof.so timeout -k 10 600 python3 tools/time_decode.py --M 20 --frames 65536 --fpw 32 --lds-level 8 --reps 1 > gpurun_out/nodeprof_r2_D.txt 2>&1 || { tail -5 gpurun_out/nodeprof_r2_D.txt; exit 1; }
-python3 tools/nodeprof_summary.py gpurun_out/nodeprof_r2_D.txt 8 30
+bash tools/prof_bench.sh r2_D --config D || exit 1
+timeout -k 10 600 python bench.py --config D --steps 5 --warmup 1 > gpurun_out/bench_r2_D.json 2> gpurun_out/bench_r2_D.err || { tail -20 gpurun_out/bench_r2_D.err; exit 1; }
+cat gpurun_out/bench_r2_D.json

@@ -28,7 +28,7 @@ for row in csv.DictReader(open(os.path.join(out, "kernel_stats.csv"))):
 vals = defaultdict(list)
 for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        if "sc_decode_kernel" in row.get("Kernel_Name", ""):
+        if "sc_decode" in row.get("Kernel_Name", ""):
             vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {}
 for k, v in sorted(vals.items()):

@@ -14,7 +14,7 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
 vals = defaultdict(list)
 for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        if "sc_decode_kernel" in row.get("Kernel_Name", ""):
+        if "sc_decode" in row.get("Kernel_Name", ""):
             vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
 print("== counters for sc_decode_kernel (per dispatch, mean over dispatches of the batch-sized launches)")
 for k in sorted(vals):

@@ -24,7 +24,8 @@ from oracle_lib import Oracle
 oracle = Oracle()
 sess = polar_amd.Session(0)
 dec = polar_amd.PolarDecoder(sess)
-variants = [(0, 0), (4, 11), (8, 10), (16, 9), (32, 8), (64, 7), (128, 6), (16, 8), (32, 7), (64, 6), (256, 5), (128, 5), (16, 10)]
+variants = [(0, 0, 1), (4, 11, 1), (8, 10, 1), (16, 9, 1), (32, 8, 1), (64, 7, 1), (128, 6, 1), (16, 8, 1), (32, 7, 1), (64, 6, 1), (256, 5, 1), (128, 5, 1), (16, 10, 1),
+            (32, 8, 4), (64, 7, 4)]  # (frames per wavefront, LDS level, team)
 rng = np.random.default_rng(a.seed)
 t0 = time.time()
 cases = 0
@@ -41,7 +42,7 @@ while time.time() - t0 < a.seconds:
     except ValueError:
         continue
     K = int((fr == 0).sum())
-    frames = int(rng.integers(1, 300))
+    frames = int(rng.integers(1, 300)) if rng.random() < 0.8 else int(rng.integers(300, 2500))  # the long ones: several teams, several sweeps
     fam = ("uniform", "small", "awgn-1")[int(rng.integers(0, 3))]
     if fam == "uniform":
         llr = rand_bytes(int(rng.integers(1 << 30)), (N, frames)).view(np.int8)
@@ -49,12 +50,12 @@ while time.time() - t0 < a.seconds:
         cw = oracle.encode(np.ones((max(K, 1), frames), np.int8)[:K], fr, M, 0)
         llr = family_llr(fam, int(rng.integers(1 << 30)), cw)
     exp = oracle.decode(llr, prog)
-    for fpw, rl in variants:
-        sess.configure(fpw, rl, int(rng.integers(0, 3)) * 8)
+    for fpw, rl, team in variants:
+        sess.configure(fpw, rl, int(rng.integers(0, 3)) * 8, team)
         out = np.zeros((max(K, 1), frames), np.int8)
         dec(out, np.ascontiguousarray(llr), prog)
         if not (out[:K] == exp).all():
-            print("MISMATCH M %d frames %d fam %s variant (%d, %d) block %d seed %d" % (M, frames, fam, fpw, rl, b, a.seed), flush=True)
+            print("MISMATCH M %d frames %d fam %s variant (%d, %d, team %d) block %d seed %d" % (M, frames, fam, fpw, rl, team, b, a.seed), flush=True)
             np.save("gpurun_out/soak_fail_frozen.npy", fr)
             sys.exit(1)
     cases += 1

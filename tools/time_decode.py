@@ -17,6 +17,7 @@ ap.add_argument("--sweeps", type=float, default=0, help="set frames to this many
 ap.add_argument("--fpw", type=int, default=0)
 ap.add_argument("--lds-level", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
+ap.add_argument("--team", type=int, default=1)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--snr", type=float, default=-1.0)
 ap.add_argument("--block-frozen", type=int, default=0, help="experiment: make the frozen set constant over 2^B-blocks (majority vote), so that no node below level B is left")
@@ -39,7 +40,7 @@ prog = np.zeros(2 * N + 1, np.uint8)
 n = polar_amd.PolarCompiler()(prog, fro, a.M)
 prog = prog[:n].copy()
 sess = polar_amd.Session(0)
-sess.configure(a.fpw, a.lds_level, a.waves)
+sess.configure(a.fpw, a.lds_level, a.waves, a.team)
 sigma = float(np.sqrt(1.0 / (2.0 * 10.0 ** (a.snr / 10.0))))
 g = torch.Generator(device="cuda").manual_seed(1)
 llr = torch.empty((N, a.frames), dtype=torch.int8, device="cuda")
