@@ -347,11 +347,14 @@ def main():
     value = total_frames * K * args.steps / elapsed / 1e9
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
+        shape = sess.last_decode_shape()
         alg = frames * 1.5 * N
         achieved = alg / (k_ms * 1e-3) / 1e9
         prof = load_profile_counters(frames, args)
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": prof.get("bytes_per_launch") if prof else None, "kernel": "sc_decode_kernel", "kernel_ms": k_ms,
+                "traffic": prof.get("bytes_per_launch") if prof else None,
+                "kernel": ("sc_decode_team_kernel<%d, %d, %d>" % (shape[0] // 4, shape[1], shape[2])) if shape[2] > 1 else "sc_decode_kernel<%d, %d>" % (shape[0] // 4, shape[1]),
+                "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": alg}
         if prof:
             # counters of the same command under rocprofv3 (profiles/): real HBM bytes per launch
@@ -371,7 +374,7 @@ def main():
                 "workload": "config %s: N=2^%d K=%d %s Const0 code, %d frames per GPU resident in HBM, BPSK/AWGN Es/N0=%.1f dB, int8 LLRs; step = %s; the timed region ends with one error count%s" % (
                     args.config, M, K, "systematic" if systematic else "non-systematic", frames, SNR_DB, what, " + RCCL all-reduce of the counters" if world > 1 else ""),
                 "frames_per_gpu": frames, "parallelism": "frames sharded over %d GPU(s)" % world,
-                "frames_per_wave": args.fpw or "default", "lds_level": args.lds_level or "default",
+                "frames_per_wave": shape[0], "lds_level": shape[1], "team": shape[2], "shape_chosen_by": "caller" if args.fpw else "library default",
             },
             "roofline": roof,
             "frac_of_hbm_roofline_whole_job": value * 1e9 * 3 / (HBM_PEAK_GBS * 1e9 * world),

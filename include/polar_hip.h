@@ -214,6 +214,10 @@ int polar_hip_simulate(polar_hip_handle *h, int program_id, const uint8_t *froze
 /* Blocks until all work enqueued through this handle has finished. */
 int polar_hip_synchronize(polar_hip_handle *h);
 
+/* The kernel shape the last polar_hip_decode / _async / polar_hip_simulate launch on this handle
+ * used: frames per wavefront, highest LLR level in LDS, team size (each pointer may be NULL). */
+int polar_hip_last_decode_shape(polar_hip_handle *h, int *frames_per_wave, int *lds_level, int *team);
+
 /* Milliseconds the GPU spent in the decode kernel of the last polar_hip_decode call, or of the
  * last chunk of the last polar_hip_simulate call (HIP events on the launch stream; the region
  * testbench.cc:170-175 times), or a negative error. */

@@ -232,6 +232,12 @@ class Session:
     def synchronize(self):
         _check(lib.polar_hip_synchronize(self._h), "polar_hip_synchronize")
 
+    def last_decode_shape(self):
+        """(frames per wavefront, LDS level, team) of the last decode launch."""
+        f, r, t = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _check(lib.polar_hip_last_decode_shape(self._h, ctypes.byref(f), ctypes.byref(r), ctypes.byref(t)), "polar_hip_last_decode_shape")
+        return f.value, r.value, t.value
+
     def last_decode_ms(self):
         ms = lib.polar_hip_last_decode_ms(self._h)
         if ms < 0:

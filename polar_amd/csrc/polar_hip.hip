@@ -706,6 +706,7 @@ struct polar_hip_handle {
 	DeviceBuffer sim_cw, sim_llr, sim_msg, sim_dec; // polar_hip_simulate's chunk
 	std::vector<uint8_t> frozen_cache; // frozen set the device tables were built from
 	int cfg_frames_per_wave = 0, cfg_lds_level = 0, cfg_team = 1, cfg_max_waves = 0;
+	int last_shape[3] = {0, 0, 0}; // frames per wavefront, LDS level, team of the last decode launch
 };
 
 static int use_device(polar_hip_handle *h)
@@ -1107,6 +1108,9 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 		blocks = blocks + 8 - blocks % 8 <= max_blocks ? blocks + 8 - blocks % 8 : blocks - blocks % 8;
 	if (getenv("POLAR_HIP_DEBUG"))
 		fprintf(stderr, "polar_hip: decode Q=%d RL=%d team=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d\n", v->q, v->rl, v->team, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct);
+	h->last_shape[0] = 4 * v->q;
+	h->last_shape[1] = v->rl;
+	h->last_shape[2] = v->team;
 	DecodeArgs a;
 	a.prog = lp.dev[shape];
 	a.cw = cw;
@@ -1252,7 +1256,7 @@ static void parallel_rows(size_t count, F fn)
 // Pageable host buffers, several chunks' worth of frames: the column block of a chunk is gathered
 // by host threads into a page-locked slot, copied in, decoded and copied out asynchronously, and
 // scattered back into the caller's rows while the next chunk is on its way.
-static int decode_host_staged(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, size_t chunk)
+static int decode_host_staged_body(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, size_t chunk)
 {
 	const HostProgram &hp = h->programs[program_id].host;
 	const size_t n = (size_t)1 << hp.top, rows = hp.rows;
@@ -1324,7 +1328,7 @@ static int decode_host_staged(polar_hip_handle *h, int program_id, int8_t *messa
 // Page-locked host buffers, several chunks' worth of frames: chunk i+1 is copied in and chunk i-1
 // copied out while chunk i decodes (three streams, two staging slots, column blocks of the
 // [rows][frames] matrices as 2D copies).
-static int decode_host_pipelined(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, size_t chunk)
+static int decode_host_pipelined_body(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, size_t chunk)
 {
 	const HostProgram &hp = h->programs[program_id].host;
 	const size_t n = (size_t)1 << hp.top, rows = hp.rows;
@@ -1356,6 +1360,29 @@ static int decode_host_pipelined(polar_hip_handle *h, int program_id, int8_t *me
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	HIP_TRY(hipStreamSynchronize(h->pipe_out));
 	return POLAR_OK;
+}
+
+// a failure in the middle of a pipeline leaves copies in flight that still name the caller's
+// buffers and the page-locked slots: let them finish before the error goes back
+static int drained(polar_hip_handle *h, int rc)
+{
+	if (rc && h->pipe_in) {
+		const std::string why = g_error;
+		(void)hipStreamSynchronize(h->pipe_in);
+		(void)hipStreamSynchronize(h->stream);
+		(void)hipStreamSynchronize(h->pipe_out);
+		(void)hipGetLastError();
+		g_error = why;
+	}
+	return rc;
+}
+static int decode_host_staged(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, size_t chunk)
+{
+	return drained(h, decode_host_staged_body(h, program_id, message, codeword, frames, chunk));
+}
+static int decode_host_pipelined(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, size_t chunk)
+{
+	return drained(h, decode_host_pipelined_body(h, program_id, message, codeword, frames, chunk));
 }
 
 extern "C" int polar_hip_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, int where)
@@ -1458,6 +1485,19 @@ extern "C" int polar_hip_decode_static(polar_hip_handle *h, int program_id, int8
 	h->timed = false;
 	hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, a);
 	HIP_TRY(hipGetLastError());
+	return POLAR_OK;
+}
+
+extern "C" int polar_hip_last_decode_shape(polar_hip_handle *h, int *frames_per_wave, int *lds_level, int *team)
+{
+	if (!h || !h->last_shape[0])
+		return fail(POLAR_E_ARG, "polar_hip_last_decode_shape: no decode on this handle");
+	if (frames_per_wave)
+		*frames_per_wave = h->last_shape[0];
+	if (lds_level)
+		*lds_level = h->last_shape[1];
+	if (team)
+		*team = h->last_shape[2];
 	return POLAR_OK;
 }
 

@@ -1488,6 +1488,8 @@ struct Group {
 				break;
 			cur = fetch(prog, pc); // fetched while the current node runs
 #ifdef POLAR_PROFILE
+			if (TEAM && lvl == top)
+				team_sync();
 			unsigned long long t0_ = __builtin_amdgcn_s_memtime();
 			node(op, lvl, hrd, row, pad);
 			__builtin_amdgcn_s_waitcnt(0);
