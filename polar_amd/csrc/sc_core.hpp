@@ -55,7 +55,10 @@ enum : u32 {
 	OP_END = 255
 };
 enum { CHAIN_MAX = 4 }; // per kernel variant: Group::CHAIN_DEPTH
-enum { SUBTREE_LEVEL = 3, SUBTREE_MAX_Q = 16 }; // OP_SUBTREE roots: level 3 (one plane octet) and level 4 (two)
+#ifndef POLAR_SUBTREE_MAX_Q
+#define POLAR_SUBTREE_MAX_Q 16
+#endif
+enum { SUBTREE_LEVEL = 3, SUBTREE_MAX_Q = POLAR_SUBTREE_MAX_Q }; // OP_SUBTREE roots: level 3 (one plane octet) and level 4 (two)
 // DevOp.pad of OP_CHAIN: bits 0-2 depth D, bits 3-4 kind of stage 1 (0 = f, 1 = g, 2 = qadd),
 // bit 4+k kind of stage k >= 2 (0 = f, 1 = qadd), bit 12+k: output of stage k is not stored (it
 // only feeds a rate0_right stage of the same chain)
