@@ -611,27 +611,94 @@ __global__ void __launch_bounds__(256) count_kernel(unsigned long long *c, const
 // ---------------------------------------------------------------------------------------
 
 // MODE 0: llr = quant(fact * (cw + sigma * n)); MODE 1: msg = 1 - 2 * bit
+// Two standard normals in single precision, for the screening pass of channel_kernel: same
+// draws, same Box-Muller as normal_pair() (channel.hpp). `ok` is cleared where single precision
+// is not good enough in absolute terms: u1 so close to 1 that r = sqrt(-2 log u1) is tiny.
+__device__ __forceinline__ void normal_pair_f32(uint32_t a, uint32_t b, float &n0, float &n1, bool &ok)
+{
+	const float S = 1.0f / 4294967296.0f;
+	ok &= a < 0xFFFE0000u; // u1 < 1 - 3e-5: r > 7e-3, its rounding error below 1e-5
+	float u1 = ((float)a + 0.5f) * S, u2 = ((float)b + 0.5f) * S;
+	float r = sqrtf(-2.0f * logf(u1)), sn, cs;
+	sincospif(2.0f * u2, &sn, &cs);
+	n0 = r * cs;
+	n1 = r * sn;
+}
+
+// MODE 0: LLRs of the noisy codeword; MODE 1: the message source. One Philox block per frame quad.
+// The LLR is quant(fact * (x + sigma * n)) in double (channel.hpp, testbench.cc:151-165), but the
+// double-precision log / sin / cos are 90 % of the bench loop's channel time. So the quad is first
+// computed in single precision (error below `thr` LLR units, see launch_channel); unless one of its
+// four values lies within `thr` of a rounding boundary k + 1/2 that result IS the double-precision
+// one after rounding, and is stored. Otherwise (a few per cent of the wavefronts) the quad is redone in
+// double. thr <= 0: double only. `wide`: whole aligned quads move as one dword.
 template <int MODE>
-__global__ void __launch_bounds__(256) channel_kernel(int8_t *out, const int8_t *cw, size_t rows, size_t frames, double sigma, double fact, uint64_t seed, uint64_t frame0)
+__global__ void __launch_bounds__(256) channel_kernel(int8_t *out, const int8_t *cw, size_t rows, size_t frames, double sigma, double fact, uint64_t seed, uint64_t frame0, float thr, int wide)
 {
 	const uint64_t q0 = frame0 >> 2, nq = ((frame0 + frames - 1) >> 2) - q0 + 1;
 	const size_t items = rows * nq, nt = (size_t)gridDim.x * blockDim.x;
+	const float sigmaf = (float)sigma, factf = (float)fact;
 	for (size_t it = (size_t)blockIdx.x * blockDim.x + threadIdx.x; it < items; it += nt) {
 		const size_t i = it / nq;
 		const uint64_t quad = q0 + it % nq;
 		PhiloxBlock b = draw(seed, MODE ? STREAM_MESSAGE : STREAM_NOISE, (uint32_t)i, quad);
-		double n[4] = {0, 0, 0, 0};
-		if (MODE == 0) {
-			normal_pair(b.v[0], b.v[1], n[0], n[1]);
-			normal_pair(b.v[2], b.v[3], n[2], n[3]);
-		}
+		const size_t at0 = i * frames + (size_t)(4 * quad - frame0); // of the quad's first frame (wide: in range)
+		int8_t res[4];
+		if (MODE == 1) {
 #pragma unroll
-		for (int c = 0; c < 4; ++c) {
-			uint64_t g = 4 * quad + c;
-			if (g < frame0 || g >= frame0 + frames)
-				continue;
-			size_t at = i * frames + (size_t)(g - frame0);
-			out[at] = MODE ? (int8_t)(1 - 2 * (int)(b.v[c] & 1)) : quant_llr(fact * ((double)cw[at] + sigma * n[c]));
+			for (int c = 0; c < 4; ++c)
+				res[c] = (int8_t)(1 - 2 * (int)(b.v[c] & 1));
+		} else {
+			int8_t x[4] = {0, 0, 0, 0};
+			if (wide) {
+				uint32_t w = *reinterpret_cast<const uint32_t *>(cw + at0);
+#pragma unroll
+				for (int c = 0; c < 4; ++c)
+					x[c] = (int8_t)(w >> (8 * c));
+			} else {
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					uint64_t g = 4 * quad + c;
+					if (g >= frame0 && g < frame0 + frames)
+						x[c] = cw[i * frames + (size_t)(g - frame0)];
+				}
+			}
+			bool ok = thr > 0.0f;
+			if (ok) {
+				float n[4];
+				normal_pair_f32(b.v[0], b.v[1], n[0], n[1], ok);
+				normal_pair_f32(b.v[2], b.v[3], n[2], n[3], ok);
+#pragma unroll
+				for (int c = 0; c < 4; ++c) {
+					float l = factf * ((float)x[c] + sigmaf * n[c]);
+					float fl = floorf(l);
+					ok &= fabsf(l - fl - 0.5f) > thr;
+					float r = fl + (l - fl > 0.5f ? 1.0f : 0.0f);
+					res[c] = (int8_t)(r < -128.0f ? -128.0f : r > 127.0f ? 127.0f : r);
+				}
+			}
+			if (!ok) {
+				double n[4];
+				normal_pair(b.v[0], b.v[1], n[0], n[1]);
+				normal_pair(b.v[2], b.v[3], n[2], n[3]);
+#pragma unroll
+				for (int c = 0; c < 4; ++c)
+					res[c] = quant_llr(fact * ((double)x[c] + sigma * n[c]));
+			}
+		}
+		if (wide) {
+			uint32_t w = 0;
+#pragma unroll
+			for (int c = 0; c < 4; ++c)
+				w |= (uint32_t)(uint8_t)res[c] << (8 * c);
+			*reinterpret_cast<uint32_t *>(out + at0) = w;
+		} else {
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				uint64_t g = 4 * quad + c;
+				if (g >= frame0 && g < frame0 + frames)
+					out[i * frames + (size_t)(g - frame0)] = res[c];
+			}
 		}
 	}
 }
@@ -1949,10 +2016,18 @@ static int launch_channel(polar_hip_handle *h, int mode, int8_t *out, const int8
 	size_t items = rows * (((frame0 + frames - 1) >> 2) - (frame0 >> 2) + 1);
 	size_t want = (items + 255) / 256, cap = (size_t)h->cus * 32;
 	unsigned blocks = (unsigned)(want < cap ? want : cap);
+	// Screening threshold in LLR units. The single-precision normal is good to 1e-5 absolute
+	// (|n| < 6.7; logf, sqrtf, sincospif within 2 ulp; u1 near 1 excluded in normal_pair_f32), which
+	// the LLR scale multiplies by fact * sigma; the LLR arithmetic itself adds 128 * 2^-22. Four
+	// times that bound is asked for. No screening when it would reject most values anyway.
+	const bool f64_only = getenv("POLAR_HIP_CHANNEL_F64") != nullptr; // tests and experiments
+	double bound = 4.0 * (1e-5 * fact * sigma + 128.0 / 4194304.0);
+	float thr = f64_only || bound > 0.05 ? 0.0f : (float)bound;
+	int wide = frames % 4 == 0 && frame0 % 4 == 0 && (uintptr_t)out % 4 == 0 && (uintptr_t)cw % 4 == 0;
 	if (mode)
-		hipLaunchKernelGGL(channel_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, out, cw, rows, frames, sigma, fact, seed, frame0);
+		hipLaunchKernelGGL(channel_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, out, cw, rows, frames, sigma, fact, seed, frame0, thr, wide);
 	else
-		hipLaunchKernelGGL(channel_kernel<0>, dim3(blocks), dim3(256), 0, h->stream, out, cw, rows, frames, sigma, fact, seed, frame0);
+		hipLaunchKernelGGL(channel_kernel<0>, dim3(blocks), dim3(256), 0, h->stream, out, cw, rows, frames, sigma, fact, seed, frame0, thr, wide);
 	HIP_TRY(hipGetLastError());
 	return POLAR_OK;
 }

@@ -457,6 +457,24 @@ def test_channel_and_message_vs_oracle(session, oracle):
     assert bool((torch.cat(parts, dim=1) == whole).all())
 
 
+def test_channel_screening_is_exact(session, monkeypatch):
+    """The channel kernel computes every quad in single precision first and keeps that result
+    unless a value lies within the error bound of a rounding boundary, where it redoes the quad
+    in double: over 2^27 samples per SNR the LLRs must equal those of the double-only kernel."""
+    rows, frames = 2048, 1 << 16
+    g = torch.Generator(device="cuda").manual_seed(4)
+    cw = (1 - 2 * torch.randint(0, 2, (rows, frames), generator=g, device="cuda", dtype=torch.int8))
+    cw[::7, ::5] = 0  # erased code symbols
+    for snr in (-3.0, -1.0, 0.5, 5.0, 12.0, 30.0):
+        fast = torch.zeros_like(cw)
+        session.channel(fast, cw, snr, 21, 4096)
+        monkeypatch.setenv("POLAR_HIP_CHANNEL_F64", "1")
+        slow = torch.zeros_like(cw)
+        session.channel(slow, cw, snr, 21, 4096)
+        monkeypatch.delenv("POLAR_HIP_CHANNEL_F64")
+        assert bool((fast == slow).all()), snr
+
+
 def test_simulate_matches_the_step_by_step_chain(session, oracle):
     """polar_hip_simulate (testbench.cc:125-193 on the device) against the same chain assembled
     from the oracle's pieces on the device-generated LLRs, both encoders, sharded and whole."""
