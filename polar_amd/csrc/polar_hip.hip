@@ -2103,6 +2103,12 @@ extern "C" int polar_hip_simulate(polar_hip_handle *h, int program_id, const uin
 		return fail(POLAR_E_NOMEM, "polar_hip_simulate: not enough device memory for one frame");
 	if (chunk > frames)
 		chunk = frames;
+	if (chunk >= 1024 && frames > chunk) { // equal chunks instead of full ones and a small rest (which would decode in the small-batch regime)
+		size_t pieces = (frames + chunk - 1) / chunk, even = (frames + pieces - 1) / pieces;
+		even = (even + 1023) / 1024 * 1024;
+		if (even < chunk)
+			chunk = even;
+	}
 	if (frames) {
 		if ((rc = h->sim_cw.reserve(n * chunk > packed_tmp_bytes(level, chunk) ? n * chunk : packed_tmp_bytes(level, chunk))) || (rc = h->sim_llr.reserve(n * chunk)) || (rc = h->sim_msg.reserve((size_t)(K ? K : 1) * chunk)) || (rc = h->sim_dec.reserve((size_t)(K ? K : 1) * chunk)))
 			return rc;
