@@ -148,6 +148,8 @@ int polar_hip_decode_f32(polar_hip_handle *h, int program_id, float *message, co
  * and the call makes no hipMalloc / hipFree / allocating library call: it only enqueues one kernel
  * on `stream`. Limits, each rejected with POLAR_E_ARG and a message:
  *   - frames must be a multiple of 32 and both pointers 16-byte aligned (no staging copies);
+ *     a multiple of 128 runs the faster team kernel (four wavefronts per workgroup) when four
+ *     arenas fit the array together, anything else one wavefront per workgroup;
  *   - one wavefront's arena, 10 * 2^level bytes, must fit the array: codes up to N = 2^22;
  *     the array bounds the resident wavefronts (25 at N = 2^16), so big codes decode slowly here;
  *   - the program must have been loaded with polar_hip_load_program (its instruction stream for

@@ -81,7 +81,7 @@ static const KernelVariant *find_variant(int q, int rl, int team = 1)
 // returned with that device current (polar_hip_create).
 enum : size_t { STATIC_SCRATCH_BYTES = (size_t)POLAR_STATIC_SCRATCH_BYTES };
 static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
-enum { MAX_DEVICES = 64, STATIC_Q = 8, STATIC_RL = 8 }; // the kernel shape of the static entry point: 32 frames per wavefront
+enum { MAX_DEVICES = 64, STATIC_Q = 8, STATIC_RL = 8, STATIC_TEAM = 4 }; // the kernel shape of the static entry point: 32 frames per wavefront, in teams of four when the batch is whole teams
 static void *g_static_scratch[MAX_DEVICES];
 
 // ---------------------------------------------------------------------------------------
@@ -907,10 +907,10 @@ extern "C" int polar_hip_create(polar_hip_handle **out, int device)
 		HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
 		g_static_scratch[device] = ptr;
 	}
-	{ // the static entry point must not meet a first-use query: resident workgroups of its kernel shape, now
-		const KernelVariant *sv = find_variant(STATIC_Q, STATIC_RL);
+	for (int team : {1, (int)STATIC_TEAM}) { // the static entry point must not meet a first-use query: resident workgroups of its kernel shapes, now
+		const KernelVariant *sv = find_variant(STATIC_Q, STATIC_RL, team);
 		int per_cu = 0;
-		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sv->fn, 64, 0));
+		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sv->fn, 64 * team, 0));
 		h->occupancy[(const void *)sv->fn] = per_cu;
 	}
 	*out = h;
@@ -1511,9 +1511,13 @@ extern "C" int polar_hip_decode_static(polar_hip_handle *h, int program_id, int8
 		return rc;
 	if (!frames)
 		return POLAR_OK;
-	const KernelVariant *v = find_variant(STATIC_Q, STATIC_RL);
+	const size_t fpw = 4 * (size_t)STATIC_Q;
 	LoadedProgram &lp = h->programs[program_id];
-	const size_t fpw = 4 * (size_t)v->q;
+	// teams of four for whole teams whose arenas fit the array together, else single wavefronts
+	const bool teams = frames % (fpw * STATIC_TEAM) == 0 &&
+		(lp.host.top <= STATIC_RL || STATIC_SCRATCH_BYTES / (scratch_bytes_per_wave(STATIC_Q, lp.host.top) * STATIC_TEAM) >= 1);
+	const KernelVariant *v = find_variant(STATIC_Q, STATIC_RL, teams ? STATIC_TEAM : 1);
+	const size_t team = (size_t)v->team;
 	if (frames % fpw || (uintptr_t)codeword % 16 || (uintptr_t)message % 16)
 		return fail(POLAR_E_ARG, "polar_hip_decode_static: frames must be a multiple of 32 and both buffers 16-byte aligned (this entry point cannot stage ragged batches: it does not allocate)");
 	void *arena = h->device < MAX_DEVICES ? g_static_scratch[h->device] : nullptr;
@@ -1526,13 +1530,13 @@ extern "C" int polar_hip_decode_static(polar_hip_handle *h, int program_id, int8
 	const size_t groups = frames / fpw;
 	if (groups > 0x7FFFFFFFu)
 		return fail(POLAR_E_ARG, "too many frames for one call");
-	size_t blocks = (size_t)occ->second * h->cus;
+	size_t blocks = (size_t)occ->second * h->cus; // workgroups of `team` wavefronts
 	DecodeArgs a;
 	a.scratch = nullptr;
 	a.block_dwords = 0;
 	if (lp.host.top > v->rl) {
 		const size_t per_wave = scratch_bytes_per_wave(v->q, lp.host.top);
-		const size_t fit = STATIC_SCRATCH_BYTES / per_wave;
+		const size_t fit = STATIC_SCRATCH_BYTES / (per_wave * team);
 		if (fit < 1)
 			return fail(POLAR_E_ARG, "polar_hip_decode_static: one wavefront of this code needs " + std::to_string(per_wave) + " bytes of scratch, the static array holds " + std::to_string((size_t)STATIC_SCRATCH_BYTES) + " (codes up to N = 2^20)");
 		if (blocks > fit)
@@ -1540,8 +1544,8 @@ extern "C" int polar_hip_decode_static(polar_hip_handle *h, int program_id, int8
 		a.scratch = (u32 *)arena; // the pointer, never the symbol
 		a.block_dwords = per_wave / sizeof(u32);
 	}
-	if (blocks > groups)
-		blocks = groups;
+	if (blocks > groups / team)
+		blocks = groups / team;
 	a.prog = dev->second;
 	a.cw = (const uint8_t *)codeword;
 	a.msg = (uint8_t *)message;
@@ -1550,7 +1554,7 @@ extern "C" int polar_hip_decode_static(polar_hip_handle *h, int program_id, int8
 	a.top = lp.host.top;
 	a.prof = nullptr;
 	h->timed = false;
-	hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, a);
+	hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64 * (unsigned)team), 0, (hipStream_t)stream, a);
 	HIP_TRY(hipGetLastError());
 	return POLAR_OK;
 }

@@ -36,8 +36,11 @@ def _pair(session, oracle, M, frames, fam, seed):
 
 
 def test_static_entry_point_matches_decode(session, oracle):
-    # first call: N = 2^14 (levels 9..13 in the static array), many groups per wavefront
+    # first call: N = 2^14 (levels 9..13 in the static array), many groups per wavefront; 700 groups
+    # are whole teams of four (the team kernel), 701 are not (single wavefronts)
     ref, got = _pair(session, oracle, 14, 32 * 700, "uniform", 3)
+    assert bool((ref == got).all())
+    ref, got = _pair(session, oracle, 14, 32 * 701, "uniform", 4)
     assert bool((ref == got).all())
     # second call, smaller input and smaller code, same array
     ref, got = _pair(session, oracle, 12, 32 * 9, "small", 5)
