@@ -633,8 +633,9 @@ __device__ __forceinline__ void normal_pair_f32(uint32_t a, uint32_t b, float &n
 // one after rounding, and is stored. Otherwise (a few per cent of the wavefronts) the quad is redone in
 // double. thr <= 0: double only. `wide`: whole aligned quads move as one dword.
 template <int MODE>
-__global__ void __launch_bounds__(256) channel_kernel(int8_t *out, const int8_t *cw, size_t rows, size_t frames, double sigma, double fact, uint64_t seed, uint64_t frame0, float thr, int wide)
+__global__ void __launch_bounds__(256) channel_kernel(int8_t *out, const int8_t *cw, size_t rows, size_t frames, double sigma, double fact, uint64_t seed, uint64_t frame0, float thr, int wide, unsigned long long *counts)
 {
+	unsigned n_flipped = 0, n_zero = 0; // counts[0] += #(llr * x < 0), counts[1] += #(llr == 0) (testbench.cc:185-188), when asked for
 	const uint64_t q0 = frame0 >> 2, nq = ((frame0 + frames - 1) >> 2) - q0 + 1;
 	const size_t items = rows * nq, nt = (size_t)gridDim.x * blockDim.x;
 	const float sigmaf = (float)sigma, factf = (float)fact;
@@ -699,6 +700,30 @@ __global__ void __launch_bounds__(256) channel_kernel(int8_t *out, const int8_t 
 				if (g >= frame0 && g < frame0 + frames)
 					out[i * frames + (size_t)(g - frame0)] = res[c];
 			}
+		}
+		if (MODE == 0 && counts) {
+#pragma unroll
+			for (int c = 0; c < 4; ++c) {
+				uint64_t g = 4 * quad + c;
+				if (wide || (g >= frame0 && g < frame0 + frames)) {
+					int xs = cw[i * frames + (size_t)(g - frame0)];
+					n_flipped += (int)res[c] * xs < 0;
+					n_zero += res[c] == 0;
+				}
+			}
+		}
+	}
+	if (MODE == 0 && counts) {
+		unsigned long long a = n_flipped, z = n_zero;
+		for (int off = 32; off; off >>= 1) {
+			a += __shfl_down(a, off, 64);
+			z += __shfl_down(z, off, 64);
+		}
+		if ((threadIdx.x & 63) == 0) {
+			if (a)
+				atomicAdd(&counts[0], a);
+			if (z)
+				atomicAdd(&counts[1], z);
 		}
 	}
 }
@@ -2014,7 +2039,7 @@ extern "C" int polar_hip_count(polar_hip_handle *h, int64_t *counters, const int
 
 // ---- message source, channel, and the whole bench loop on the device ----
 
-static int launch_channel(polar_hip_handle *h, int mode, int8_t *out, const int8_t *cw, size_t rows, size_t frames, double snr_db, uint64_t seed, uint64_t frame0)
+static int launch_channel(polar_hip_handle *h, int mode, int8_t *out, const int8_t *cw, size_t rows, size_t frames, double snr_db, uint64_t seed, uint64_t frame0, unsigned long long *counts = nullptr)
 {
 	double sigma = channel_sigma(snr_db), fact = 2.0 / (sigma * sigma);
 	size_t items = rows * (((frame0 + frames - 1) >> 2) - (frame0 >> 2) + 1);
@@ -2029,9 +2054,9 @@ static int launch_channel(polar_hip_handle *h, int mode, int8_t *out, const int8
 	float thr = f64_only || bound > 0.05 ? 0.0f : (float)bound;
 	int wide = frames % 4 == 0 && frame0 % 4 == 0 && (uintptr_t)out % 4 == 0 && (uintptr_t)cw % 4 == 0;
 	if (mode)
-		hipLaunchKernelGGL(channel_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, out, cw, rows, frames, sigma, fact, seed, frame0, thr, wide);
+		hipLaunchKernelGGL(channel_kernel<1>, dim3(blocks), dim3(256), 0, h->stream, out, cw, rows, frames, sigma, fact, seed, frame0, thr, wide, counts);
 	else
-		hipLaunchKernelGGL(channel_kernel<0>, dim3(blocks), dim3(256), 0, h->stream, out, cw, rows, frames, sigma, fact, seed, frame0, thr, wide);
+		hipLaunchKernelGGL(channel_kernel<0>, dim3(blocks), dim3(256), 0, h->stream, out, cw, rows, frames, sigma, fact, seed, frame0, thr, wide, counts);
 	HIP_TRY(hipGetLastError());
 	return POLAR_OK;
 }
@@ -2125,9 +2150,7 @@ extern "C" int polar_hip_simulate(polar_hip_handle *h, int program_id, const uin
 			return rc;
 		if ((rc = encode_device(h, systematic, cw, msg, level, f)))
 			return rc;
-		if ((rc = launch_channel(h, 0, llr, cw, n, f, snr_db, seed, f0)))
-			return rc;
-		if ((rc = count_device(h, c, (const uint8_t *)llr, (const uint8_t *)cw, n * f, nullptr, nullptr, 0)))
+		if ((rc = launch_channel(h, 0, llr, cw, n, f, snr_db, seed, f0, c))) // counts the channel errors and erasures as it goes
 			return rc;
 		if ((rc = launch_decode(h, program_id, dec, llr, f, h->stream, true))) // timed: polar_hip_last_decode_ms reports the last chunk
 			return rc;
