@@ -83,12 +83,12 @@ def test_decoder_vs_oracle_all_variants(session, oracle, fpw, rl, team):
         session.configure(0, 0, 0)
 
 
-@pytest.mark.parametrize("fpw,rl,team", [(128, 6, 1), (128, 5, 1), (64, 7, 1), (256, 5, 1), (64, 7, 4), (32, 8, 4)])
-def test_wide_variants_full_size_digest(session, oracle, golden, fpw, rl, team):
-    """The variants the default picks for big batches, on the reference's N = 2^16 digests: the
-    32 golden frames are embedded in a batch wide enough for whole 128/256-frame groups."""
+@pytest.mark.parametrize("M,fpw,rl,team", [(16, 128, 6, 1), (16, 128, 5, 1), (16, 64, 7, 1), (16, 256, 5, 1), (16, 64, 7, 4), (16, 32, 8, 4), (20, 32, 8, 4), (20, 64, 7, 4)])
+def test_wide_variants_full_size_digest(session, oracle, golden, M, fpw, rl, team):
+    """The variants the default picks for big batches, on the reference's N = 2^16 digests (and
+    N = 2^20 for the team kernels, what config D runs): the 32 golden frames are embedded in a
+    batch wide enough for whole 128/256-frame groups."""
     meta, _ = golden
-    M = 16
     N = 1 << M
     fro = _code(oracle, M)
     prog = oracle.compile(fro, M)
