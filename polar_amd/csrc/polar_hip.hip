@@ -1119,13 +1119,13 @@ static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, siz
 	// Measured (tools/gpu_sweep_pick.sh, tools/gpu_team*.sh): a wavefront walks
 	// the program in about the same time whatever its width, so the widest group wins as soon as
 	// every resident wavefront has one -- two for 128 frames, whose one-sweep batches the 64-frame
-	// teams decode faster; groups of at most 32 frames already pay off when half of the wavefronts
-	// have one. Groups of 32 and 64 frames go in teams of four (whole 128-byte input lines).
+	// teams decode faster; groups of 32 frames already pay off when three eighths of the wavefronts
+	// have one, narrower ones when half of them do. Groups of 32 and 64 frames go in teams of four (whole 128-byte input lines).
 	const size_t resident = (size_t)8 * h->cus;
 	static const int family[][3] = {{32, 6, 1}, {16, 7, 4}, {8, 8, 4}, {4, 9, 1}, {2, 10, 1}, {1, 11, 1}};
 	for (const auto &f : family) {
 		size_t groups = (frames + 4 * f[0] - 1) / (4 * f[0]);
-		if (f[0] > 1 && groups < (f[0] == 32 ? 2 * resident : f[0] <= 8 ? resident / 2 : resident))
+		if (f[0] > 1 && groups < (f[0] == 32 ? 2 * resident : f[0] == 8 ? resident * 3 / 8 : f[0] < 8 ? resident / 2 : resident))
 			continue;
 		if (f[0] > 1 && top > f[1] && !budget.fits(resident * scratch_bytes_per_wave(f[0], top)))
 			continue;
