@@ -45,6 +45,34 @@ int main()
 	printf("program length = %d, uncorrected errors = %ld\n", length, errors);
 	if (errors)
 		return 1;
+	// the same frames, tiled over page-locked buffers (instead of the bench's aligned_alloc,
+	// testbench.cc:72,92-93): several chunks' worth, so the call overlaps its PCIe copies with the
+	// decoding; every frame must decode as its twin did above
+	setenv("POLAR_HIP_HOST_CHUNK", "1024", 1); // tests only: chunks of 1024 frames instead of 1 GiB
+	const int W2 = 3 * 1024 + 40;
+	typedef GPU<int8_t, W2> wide_type;
+	for (int i = 0; i < W * N; ++i)
+		codeword[i] = (int8_t)(orig[i] * ((i % 97) == 5 ? -9 : 24));
+	decode(reinterpret_cast<simd_type *>(decoded.data()), reinterpret_cast<simd_type *>(codeword.data()), program.data());
+	int8_t *llr2 = (int8_t *)polar_hip_host_alloc((size_t)W2 * N), *dec2 = (int8_t *)polar_hip_host_alloc((size_t)W2 * K);
+	if (!llr2 || !dec2) {
+		printf("polar_hip_host_alloc failed: %s\n", polar_hip_last_error());
+		return 1;
+	}
+	for (int i = 0; i < N; ++i)
+		for (int k = 0; k < W2; ++k)
+			llr2[(size_t)W2 * i + k] = codeword[W * i + k % W];
+	memset(dec2, 0, (size_t)W2 * K);
+	PolarDecoder<wide_type, M> decode_wide;
+	decode_wide(reinterpret_cast<wide_type *>(dec2), reinterpret_cast<wide_type *>(llr2), program.data());
+	for (int j = 0; j < K; ++j)
+		for (int k = 0; k < W2; ++k)
+			if (dec2[(size_t)W2 * j + k] != decoded[W * j + k % W]) {
+				printf("page-locked batch differs at row %d frame %d\n", j, k);
+				return 1;
+			}
+	polar_hip_host_free(llr2);
+	polar_hip_host_free(dec2);
 	printf("dropin ok\n");
 	return 0;
 }
