@@ -290,9 +290,16 @@ __global__ void __launch_bounds__(256) butterfly_kernel(T *cw, const T *msg, con
 struct PackedRow { u32 neg, nz; };
 
 // bit 7 of the four bytes of x -> bits 0..3
-__device__ __forceinline__ u32 gather_msb(u32 x) { return ((((x >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 15u; }
+// (shifts and ors: a 32-bit multiply runs at a quarter of their rate)
+__device__ __forceinline__ u32 gather_msb(u32 x)
+{
+	u32 t = (x >> 7) & 0x01010101u;
+	return (t | (t >> 7) | (t >> 14) | (t >> 21)) & 15u;
+}
 // bits 0..3 -> bit 0 of the four bytes
-__device__ __forceinline__ u32 spread_lsb(u32 nib) { return (nib * 0x00204081u) & 0x01010101u; }
+__device__ __forceinline__ u32 spread_lsb(u32 nib) { return (nib | (nib << 7) | (nib << 14) | (nib << 21)) & 0x01010101u; }
+// 0xFF in every byte whose bit 0 is set (bytes are 0 or 1)
+__device__ __forceinline__ u32 byte_fill(u32 lsb) { return (lsb << 8) - lsb; }
 
 // ragged batches / unaligned buffers: byte by byte, kept out of line so that the unrolled passes stay small
 __device__ __noinline__ PackedRow pack_symbols_slow(const uint8_t *row, size_t f0, size_t frames)
@@ -337,7 +344,7 @@ __device__ __forceinline__ void unpack_symbols(uint8_t *row, size_t f0, size_t f
 		u32 w[8];
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
-			u32 ng = spread_lsb((r.neg >> (4 * k)) & 15u) * 0xFFu, nz = spread_lsb((r.nz >> (4 * k)) & 15u) * 0xFFu;
+			u32 ng = byte_fill(spread_lsb((r.neg >> (4 * k)) & 15u)), nz = byte_fill(spread_lsb((r.nz >> (4 * k)) & 15u));
 			w[k] = nz & (ng | 0x01010101u);
 		}
 		u32x4 a, b;
@@ -1810,7 +1817,10 @@ static int packed_transform(polar_hip_handle *h, PackedPass a, int level, int lo
 		static const int smax = getenv("POLAR_HIP_TILE_S") ? atoi(getenv("POLAR_HIP_TILE_S")) : 8;
 		const int passes = level <= single ? 1 : (level + smax - 1) / smax;
 		for (int s0 = 0, pass = 0; s0 < level; ++pass) {
-			const int S = (level - s0 + (passes - pass) - 1) / (passes - pass);
+			int S = (level - s0 + (passes - pass) - 1) / (passes - pass);
+			if (const char *e = getenv("POLAR_HIP_TILE_FIRST")) // experiments only: stages of the first pass
+				if (pass == 0 && passes == 2 && atoi(e) >= 4 && atoi(e) <= 10 && level - atoi(e) >= 4 && level - atoi(e) <= 10)
+					S = atoi(e);
 			const bool last = s0 + S >= level;
 			int CW = TILE_ITEMS >> S > 64 ? 64 : TILE_ITEMS >> S;
 			while (CW > 1 && (size_t)CW / 2 >= a.cols)
