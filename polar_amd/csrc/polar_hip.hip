@@ -485,7 +485,10 @@ __device__ __forceinline__ void packed_store(const PackedPass &a, size_t row, si
 // between such phases the tile goes through LDS and the threads regroup. The last phase takes the
 // top four bits and skips the stages already done. Global accesses are CW * 8 bytes (CW * 32 for
 // symbols) contiguous per row.
-enum { TILE_ITEMS = 4096, TILE_ROWS = 16 };
+#ifndef POLAR_TILE_ITEMS
+#define POLAR_TILE_ITEMS 4096
+#endif
+enum { TILE_ITEMS = POLAR_TILE_ITEMS, TILE_ROWS = 16 };
 __global__ void __launch_bounds__(TILE_ITEMS / TILE_ROWS) packed_tile_kernel(PackedPass a)
 {
 	__shared__ u32 tile_neg[TILE_ITEMS], tile_nz[TILE_ITEMS];
