@@ -16,6 +16,8 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=60)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--min-m", type=int, default=3)
+ap.add_argument("--max-m", type=int, default=12)
 a = ap.parse_args()
 import polar_amd
 from inputs import family_llr, rand_bytes
@@ -30,7 +32,7 @@ rng = np.random.default_rng(a.seed)
 t0 = time.time()
 cases = 0
 while time.time() - t0 < a.seconds:
-    M = int(rng.integers(3, 13))
+    M = int(rng.integers(a.min_m, a.max_m + 1))
     N = 1 << M
     b = 1 << int(rng.integers(0, min(M, 6) + 1))
     fr = np.repeat((rng.random(N // b) < rng.random()).astype(np.uint8), b)
