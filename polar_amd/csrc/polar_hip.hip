@@ -2,9 +2,12 @@
 //
 //   sc_decode_kernel        : batched SC decoder, one wavefront per group of 4*Q frames (decode_kernel.hpp,
 //                             sc_core.hpp, variants.hip; replaces PolarDecoder::operator(), polar_decoder.hh:131)
+//   sc_decode_team_kernel   : the same with four wavefronts per workgroup that share the input lines (32- and 64-frame groups)
 //   sc_decode_f32_kernel    : the reference's float helper per lane (polar_helper.hh:62-111)
-//   butterfly_kernel        : polar transform stages for the encoders (polar_encoder.hh:15-58)
-//   packed_transform_kernel : systematic extraction = re-encode + gather on bit-packed symbols (testbench.cc:177-183)
+//   packed_tile_kernel      : polar transform on bit-packed symbols through LDS tiles: the encoders (polar_encoder.hh:15-58)
+//                             and the systematic extraction = re-encode + gather (testbench.cc:177-183)
+//   packed_transform_kernel : the same in registers only (codes below N = 2^6)
+//   butterfly_kernel        : transform stages on byte symbols (encoders on ragged batches)
 //   channel_kernel, count_kernel : the bench's message source, AWGN channel and error counters (testbench.cc:112-192)
 //
 // Everything here fails loudly: there is no CPU fallback for any device entry point.
