@@ -11,7 +11,8 @@
 // TYPE = GPU<int8_t, W>: a lane bundle of W frames, laid out exactly like the reference's
 // SIMD<int8_t, W> (W consecutive bytes = one code element of W frames, testbench.cc:134-139),
 // so caller code that sizes and casts buffers with sizeof(TYPE) keeps working; W is no longer
-// limited by a vector register (thousands to millions of frames per call).
+// limited by a vector register (thousands to millions of frames per call). The buffers of one call
+// may be host memory (as in the reference) or device memory (hipMalloc): polar_hip_where() tells.
 //
 // The reference has no error channel; misuse trips assert. Same here: a failing C ABI call
 // prints polar_hip_last_error() and aborts.
@@ -99,7 +100,7 @@ class PolarEncoder<GPU<int8_t, W>, M>
 public:
 	void operator()(TYPE *codeword, const TYPE *message, const uint8_t *frozen)
 	{
-		polar_amd_detail::check(polar_hip_encode(polar_amd_detail::context(), 0, (int8_t *)codeword, (const int8_t *)message, frozen, M, W, POLAR_HOST), "PolarEncoder");
+		polar_amd_detail::check(polar_hip_encode(polar_amd_detail::context(), 0, (int8_t *)codeword, (const int8_t *)message, frozen, M, W, polar_hip_where(codeword)), "PolarEncoder");
 	}
 };
 
@@ -110,7 +111,7 @@ class PolarSysEnc<GPU<int8_t, W>, M>
 public:
 	void operator()(TYPE *codeword, const TYPE *message, const uint8_t *frozen)
 	{
-		polar_amd_detail::check(polar_hip_encode(polar_amd_detail::context(), 1, (int8_t *)codeword, (const int8_t *)message, frozen, M, W, POLAR_HOST), "PolarSysEnc");
+		polar_amd_detail::check(polar_hip_encode(polar_amd_detail::context(), 1, (int8_t *)codeword, (const int8_t *)message, frozen, M, W, polar_hip_where(codeword)), "PolarSysEnc");
 	}
 };
 
@@ -154,6 +155,6 @@ public:
 			ids[next] = program_id;
 			next = (next + 1) % REMEMBERED;
 		}
-		polar_amd_detail::check(polar_hip_decode(polar_amd_detail::context(), program_id, (int8_t *)message, (const int8_t *)codeword, W, POLAR_HOST), "PolarDecoder");
+		polar_amd_detail::check(polar_hip_decode(polar_amd_detail::context(), program_id, (int8_t *)message, (const int8_t *)codeword, W, polar_hip_where(codeword)), "PolarDecoder");
 	}
 };

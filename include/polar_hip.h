@@ -120,6 +120,11 @@ int polar_hip_code(polar_hip_handle *h, int level, int K, long double erasure_pr
  * least two chunks. */
 int polar_hip_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, int where);
 
+/* POLAR_DEVICE when `ptr` is device memory (hipMalloc), POLAR_HOST otherwise (pageable or
+ * page-locked host memory, NULL): what to pass as `where`. polar.hh uses it so that the functors
+ * take buffers on either side. */
+int polar_hip_where(const void *ptr);
+
 /* Page-locked host memory for frame buffers, in place of the aligned_alloc of
  * testbench.cc:72,92-93,100-103, so that polar_hip_decode takes the overlapped path above
  * (hipHostMalloc / hipHostFree for callers that do not include HIP headers; 4 KiB aligned).

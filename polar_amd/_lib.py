@@ -28,6 +28,7 @@ SYMBOLS = {
     "polar_hip_load_program": ([_vp, _vp, _i], _i),
     "polar_hip_code": ([_vp, _i, _i, _ld, ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
     "polar_hip_decode": ([_vp, _i, _vp, _vp, _sz, _i], _i),
+    "polar_hip_where": ([_vp], _i),
     "polar_hip_host_alloc": ([_sz], _vp),
     "polar_hip_host_free": ([_vp], None),
     "polar_hip_decode_async": ([_vp, _i, _vp, _vp, _sz, _vp], _i),

@@ -1306,6 +1306,16 @@ static size_t pipeline_chunk(size_t n)
 	return c - c % 512;
 }
 
+extern "C" int polar_hip_where(const void *ptr)
+{
+	hipPointerAttribute_t attr;
+	if (!ptr || hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+		(void)hipGetLastError(); // pageable host memory is "invalid value" to this query
+		return POLAR_HOST;
+	}
+	return attr.type == hipMemoryTypeDevice ? POLAR_DEVICE : POLAR_HOST;
+}
+
 extern "C" void *polar_hip_host_alloc(size_t bytes)
 {
 	void *p = nullptr;

@@ -610,3 +610,8 @@ def test_cpp_dropin_header():
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "dropin ok" in r.stdout, r.stdout + r.stderr
+    # the same functors on buffers the caller keeps in device memory (tests/cpp/dropin_device_test.cc)
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_device_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "dropin device ok" in r.stdout, r.stdout + r.stderr
