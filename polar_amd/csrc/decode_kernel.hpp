@@ -18,6 +18,9 @@ struct DecodeArgs {
 	size_t stride;         // bytes per row of cw and msg: a multiple of 4, groups * 4Q <= stride
 	u32 groups;
 	int top;
+	int hot_top;           // scratch levels up to this one keep the default cache policy (sc_core.hpp, GVec::hot) ...
+	u32 *hot;              // ... and live here: one block of hot_dwords per wavefront, side by side
+	size_t hot_dwords;     // (Q << (hot_top + 1)) - (Q << (RL + 1)), 0 when there is no hot level
 	unsigned long long *prof; // diagnostic build (POLAR_PROFILE) only
 };
 
@@ -44,6 +47,8 @@ __global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
 	g.hgs = arena ? arena + ((size_t)Q << a.top) : nullptr;
 	g.hgz = arena ? g.hgs + plane : nullptr;
 	g.top = a.top;
+	g.hot_top = a.hot_top;
+	g.sh = a.hot ? a.hot + (size_t)b * a.hot_dwords - ((size_t)Q << (RL + 1)) : nullptr;
 #ifdef POLAR_PROFILE
 	g.prof = a.prof;
 #endif
@@ -79,6 +84,8 @@ __global__ void __launch_bounds__(64 * TEAM_WAVES, 2) sc_decode_team_kernel(Deco
 	g.hgs = arena ? arena + ((size_t)Q << a.top) : nullptr;
 	g.hgz = arena ? g.hgs + plane : nullptr;
 	g.top = a.top;
+	g.hot_top = a.hot_top;
+	g.sh = a.hot ? a.hot + ((size_t)b * TEAM_WAVES + w) * a.hot_dwords - ((size_t)Q << (RL + 1)) : nullptr;
 #ifdef POLAR_PROFILE
 	g.prof = a.prof;
 #endif

@@ -807,7 +807,7 @@ struct polar_hip_handle {
 		bool operator<(const CodeKey &o) const { return level != o.level ? level < o.level : K != o.K ? K < o.K : p < o.p; }
 	};
 	std::map<CodeKey, CachedCode> codes; // polar_hip_code: (level, K, p) -> frozen set, program, resident id
-	DeviceBuffer scratch, stage_in, stage_out, enc_tmp, tables, counters, pad_in, pad_out;
+	DeviceBuffer scratch, hot, stage_in, stage_out, enc_tmp, tables, counters, pad_in, pad_out;
 	DeviceBuffer sim_cw, sim_llr, sim_msg, sim_dec; // polar_hip_simulate's chunk
 	std::vector<uint8_t> frozen_cache; // frozen set the device tables were built from
 	int cfg_frames_per_wave = 0, cfg_lds_level = 0, cfg_team = 1, cfg_max_waves = 0;
@@ -976,6 +976,7 @@ extern "C" void polar_hip_destroy(polar_hip_handle *h)
 	h->tables.release();
 	h->counters.release();
 	h->pad_in.release();
+	h->hot.release();
 	h->pad_out.release();
 	h->sim_cw.release();
 	h->sim_llr.release();
@@ -1125,6 +1126,32 @@ extern "C" int polar_hip_code(polar_hip_handle *h, int level, int K, long double
 	return it->second.program_id;
 }
 
+// Highest scratch level that keeps the default cache policy (sc_core.hpp, GVec::hot): the levels just
+// above the LDS levels, as many as the Infinity Cache holds for all resident wavefronts together
+// (wavefronts * frames per wavefront * 2^level bytes per level).
+// Their vectors are read back and rewritten in place before the streamed (non-temporal) levels above
+// can displace them, so they never travel to HBM (tools/ubench/hbm_ceiling.hip).
+static int hot_top_for(const KernelVariant *v, int top, size_t waves)
+{
+	if (v->team > 1) // the team kernels are built without hot levels (sc_core.hpp, Group::HOT)
+		return v->rl;
+	static const char *e = getenv("POLAR_HIP_HOT_LEVELS"); // experiments: number of hot levels
+	if (e)
+		return v->rl + atoi(e);
+	static const char *b = getenv("POLAR_HIP_HOT_BYTES"); // experiments: cache budget in MiB
+	const size_t budget = (b ? (size_t)atoi(b) : (size_t)480) << 20;
+	size_t used = 0;
+	int lvl = v->rl;
+	while (lvl + 1 < top) {
+		size_t bytes = waves * 4 * (size_t)v->q << (lvl + 1);
+		if (used + bytes > budget)
+			break;
+		used += bytes;
+		++lvl;
+	}
+	return lvl;
+}
+
 static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, size_t frames, ScratchBudget &budget)
 {
 	if (h->cfg_frames_per_wave)
@@ -1212,7 +1239,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	if (blocks >= 8 && blocks % 8) // multiple of 8 for the XCD-aware group order
 		blocks = blocks + 8 - blocks % 8 <= max_blocks ? blocks + 8 - blocks % 8 : blocks - blocks % 8;
 	if (getenv("POLAR_HIP_DEBUG"))
-		fprintf(stderr, "polar_hip: decode Q=%d RL=%d team=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d\n", v->q, v->rl, v->team, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct);
+		fprintf(stderr, "polar_hip: decode Q=%d RL=%d team=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d hot levels <= %d\n", v->q, v->rl, v->team, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct, hot_top_for(v, lp.host.top, blocks * team));
 	h->last_shape[0] = 4 * v->q;
 	h->last_shape[1] = v->rl;
 	h->last_shape[2] = v->team;
@@ -1223,6 +1250,9 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	a.stride = padded;
 	a.groups = (u32)groups;
 	a.top = lp.host.top;
+	a.hot_top = v->rl;
+	a.hot = nullptr;
+	a.hot_dwords = 0;
 	a.scratch = nullptr;
 	a.block_dwords = 0;
 	if (block_dwords) {
@@ -1230,6 +1260,13 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 		if ((rc = h->scratch.reserve(blocks * team * block_dwords * sizeof(u32))))
 			return rc;
 		a.scratch = (u32 *)h->scratch.p;
+		a.hot_top = hot_top_for(v, lp.host.top, blocks * team);
+		if (a.hot_top > v->rl) { // the wavefronts' hot levels side by side in one compact region
+			a.hot_dwords = ((size_t)v->q << (a.hot_top + 1)) - ((size_t)v->q << (v->rl + 1));
+			if ((rc = h->hot.reserve(blocks * team * a.hot_dwords * sizeof(u32))))
+				return rc;
+			a.hot = (u32 *)h->hot.p;
+		}
 	}
 	a.prof = nullptr;
 #ifdef POLAR_PROFILE
@@ -1600,6 +1637,9 @@ extern "C" int polar_hip_decode_static(polar_hip_handle *h, int program_id, int8
 	a.stride = frames;
 	a.groups = (u32)groups;
 	a.top = lp.host.top;
+	a.hot_top = v->rl; // no hot region here: it would have to be carved out of the static array
+	a.hot = nullptr;
+	a.hot_dwords = 0;
 	a.prof = nullptr;
 	h->timed = false;
 	hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64 * (unsigned)team), 0, (hipStream_t)stream, a);

@@ -54,6 +54,9 @@ enum : u32 {
 	OP_SUBTREE = 17,
 	OP_END = 255
 };
+#ifndef POLAR_HOT_ENABLE
+#define POLAR_HOT_ENABLE 1
+#endif
 enum { CHAIN_MAX = 4 }; // per kernel variant: Group::CHAIN_DEPTH
 #ifndef POLAR_SUBTREE_MAX_Q
 #define POLAR_SUBTREE_MAX_Q 16
@@ -216,20 +219,63 @@ PDEV u32x4 qadd4(u32x4 a, u32x4 b) { u32x4 r; r.x = qadd4(a.x, b.x); r.y = qadd4
 // the same wavefront, far beyond what L2 or the Infinity Cache can hold in between. Marking the
 // 16-byte accesses non-temporal keeps them from evicting lines that do get reused (+8 % at
 // N = 2^16). POLAR_NO_NT restores default-policy accesses for comparison.
+#ifndef POLAR_EMU
+typedef __attribute__((address_space(1))) u32 glb_u32;
+typedef __attribute__((address_space(1))) u32x4 glb_u32x4;
+#else
+typedef u32 glb_u32;
+typedef u32x4 glb_u32x4;
+#endif
+// Keeps the optimiser from folding "hot ? default-policy access : non-temporal access" into ONE
+// access of a selected address, which silently loses the non-temporal hint (the (128, 6) kernel went
+// from 197 non-temporal 16-byte stores to 12 that way, and the streamed levels then displaced the hot
+// ones from the cache): an empty volatile asm before and after the default-policy side makes that
+// block unspeculatable and unlike its twin. It emits no instruction.
+#ifndef POLAR_EMU
+#define POLAR_KEEP_APART() asm volatile("")
+#else
+#define POLAR_KEEP_APART() ((void)0)
+#endif
 struct GVec { // linear dword array in the HBM scratch arena
-	u32 *p;
+	glb_u32 *p;
+	// hot: a level just above the LDS levels. Its vector is read back a few tens of microseconds after
+	// it was written and rewritten in place soon after: with the default cache policy it lives in the
+	// Infinity Cache (and never reaches HBM), as long as the streamed levels above it stay non-temporal
+	// and so do not displace it (tools/ubench/sc_skeleton.hip). Wave-uniform.
+	bool hot;
 	PDEV u32 ld(int t) const { return p[t]; }
 	PDEV void st(int t, u32 v) const { p[t] = v; }
+	PDEV u32x4 ld4h(int t) const { return *reinterpret_cast<const glb_u32x4 *>(p + t); }
+	PDEV void st4h(int t, u32x4 v) const { *reinterpret_cast<glb_u32x4 *>(p + t) = v; }
 #if !defined(POLAR_EMU) && !defined(POLAR_NO_NT)
-	PDEV u32x4 ld4(int t) const { return __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p + t)); }
+	PDEV u32x4 ld4c(int t) const { return __builtin_nontemporal_load(reinterpret_cast<const glb_u32x4 *>(p + t)); }
+	PDEV void st4c(int t, u32x4 v) const { __builtin_nontemporal_store(v, reinterpret_cast<glb_u32x4 *>(p + t)); }
 #else
-	PDEV u32x4 ld4(int t) const { return *reinterpret_cast<const u32x4 *>(p + t); }
+	PDEV u32x4 ld4c(int t) const { return ld4h(t); }
+	PDEV void st4c(int t, u32x4 v) const { st4h(t, v); }
 #endif
-#if !defined(POLAR_EMU) && !defined(POLAR_NO_NT)
-	PDEV void st4(int t, u32x4 v) const { __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p + t)); }
-#else
-	PDEV void st4(int t, u32x4 v) const { *reinterpret_cast<u32x4 *>(p + t) = v; }
-#endif
+	PDEV u32x4 ld4(int t) const
+	{
+		u32x4 r;
+		if (hot) {
+			POLAR_KEEP_APART();
+			r = ld4h(t);
+			POLAR_KEEP_APART();
+		} else {
+			r = ld4c(t);
+		}
+		return r;
+	}
+	PDEV void st4(int t, u32x4 v) const
+	{
+		if (hot) {
+			POLAR_KEEP_APART();
+			st4h(t, v);
+			POLAR_KEEP_APART();
+		} else {
+			st4c(t, v);
+		}
+	}
 };
 
 struct LVec { // linear dword array in LDS
@@ -272,12 +318,29 @@ template <int Q, bool NT = true> struct InVec {
 template <int Q> struct OutRows { // the caller's message buffer, same row layout
 	uint8_t *p;
 	size_t stride;
+	// message rows are written once and never read by the kernel: non-temporal where a group's row
+	// segment is a whole 128-byte line, so that they do not displace the hot scratch levels from the
+	// caches. Narrower groups leave them to L2, which merges the neighbouring groups' parts of a line
+	// (non-temporal partial lines: (64, 7) teams 124 -> 155 ms, measured).
+	static const bool NT = Q % 32 == 0;
 	PDEV void st(u32 row, int q, u32 v) const
 	{
+#if !defined(POLAR_EMU) && !defined(POLAR_NO_NT)
+		if (NT) {
+			__builtin_nontemporal_store(v, reinterpret_cast<u32 *>(p + (size_t)row * stride + 4 * q));
+			return;
+		}
+#endif
 		*reinterpret_cast<u32 *>(p + (size_t)row * stride + 4 * q) = v;
 	}
 	PDEV void st4(u32 row, int q, u32x4 v) const // q % 4 == 0, Q % 4 == 0
 	{
+#if !defined(POLAR_EMU) && !defined(POLAR_NO_NT)
+		if (NT) {
+			__builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(p + (size_t)row * stride + 4 * q));
+			return;
+		}
+#endif
 		*reinterpret_cast<u32x4 *>(p + (size_t)row * stride + 4 * q) = v;
 	}
 };
@@ -299,6 +362,30 @@ PDEV void stp4s(lds_u32 *p, u32x4 v) { stp4(p, v); }
 template <class T> PDEV u32x4 ldp4s(const T *p) { return ldp4(p); }
 template <class T> PDEV void stp4s(T *p, u32x4 v) { stp4(p, v); }
 #endif
+
+// 16-byte plane accesses with the policy chosen at run time (hot: default, else streaming)
+template <class T> PDEV u32x4 ldp4p(const T *p, bool hot)
+{
+	u32x4 r;
+	if (hot) {
+		POLAR_KEEP_APART();
+		r = ldp4(p);
+		POLAR_KEEP_APART();
+	} else {
+		r = ldp4s(p);
+	}
+	return r;
+}
+template <class T> PDEV void stp4p(T *p, u32x4 v, bool hot)
+{
+	if (hot) {
+		POLAR_KEEP_APART();
+		stp4(p, v);
+		POLAR_KEEP_APART();
+	} else {
+		stp4s(p, v);
+	}
+}
 
 template <class A> struct SrcIsLds { static const bool value = false; };
 template <> struct SrcIsLds<LVec> { static const bool value = true; };
@@ -350,6 +437,7 @@ struct Group {
 	lds_u32 *sl;        // LDS soft arena, LDS_SOFT dwords (level l at Q << l)
 	lds_u32 *hls, *hlz; // LDS partial-sum planes (sign, zero), LDS_PLANE dwords each, index by position mod W
 	u32 *sg;            // scratch soft arena, Q << top dwords
+	u32 *sh;            // hot levels (RL+1 .. hot_top): level l at sh + (Q << l), inside this wavefront's block of the compact hot region
 	u32 *hgs, *hgz;     // scratch partial-sum planes, (Q << top) / 8 dwords each
 	In in;
 	OutRows<Q> out;
@@ -359,10 +447,20 @@ struct Group {
 	// plane; zl = the same for the completed left child waiting at level l. Clear bit: the
 	// plane words of that node are undefined and read as "no erasure". Wave-uniform.
 	u32 zc, zl;
+	int hot_top; // scratch levels RL+1 .. hot_top keep the default cache policy (GVec::hot), the ones above stream
 #ifdef POLAR_PROFILE
 	unsigned long long *prof; // [16 node kinds][32 levels][cycles, calls], diagnostic build only
 #endif
 
+	// level-lvl LLR region in scratch. The hot levels of all resident wavefronts lie side by side in
+	// one compact region: spread over the per-wave arenas (10 MiB apart at N = 2^16) they fall into a
+	// fraction of the Infinity Cache's sets and evict one another (tools/ubench/sc_skeleton.hip:
+	// 5.5 TB/s spread, 6.6 TB/s compact for the same accesses).
+	// Not in the team kernels: they sit at the 256-register limit and the second code path spills.
+	static const bool HOT = !TEAM && POLAR_HOT_ENABLE;
+	PDEV bool is_hot(int lvl) const { return HOT && lvl <= hot_top; }
+	PDEV u32 *gregion(int lvl) const { return (is_hot(lvl) ? sh : sg) + (Q << lvl); }
+	PDEV GVec gvec(int lvl) const { return GVec{(glb_u32 *)gregion(lvl), is_hot(lvl)}; }
 	// plane dword of element e for frame quad q
 	static PDEV int pidx(u32 e, int q) { return (int)(e >> 3) * Q + q; }
 
@@ -378,7 +476,7 @@ struct Group {
 	PDEV u32 *fregion(int lvl) const // flat pointer to the level-lvl LLR region (lvl < top)
 	{
 		if (lvl > RL)
-			return sg + (Q << lvl);
+			return gregion(lvl);
 		return (u32 *)sl + (Q << lvl);
 	}
 
@@ -418,15 +516,15 @@ struct Group {
 			if (lvl == top)
 				pass<KIND>(in, d, n, hls, hlz, eb);
 			else if (lvl > RL)
-				pass<KIND>(GVec{sg + 2 * n}, d, n, hls, hlz, eb);
+				pass<KIND>(gvec(lvl), d, n, hls, hlz, eb);
 			else
 				pass<KIND>(LVec{sl + 2 * n}, d, n, hls, hlz, eb);
 		} else {
-			GVec d{sg + n};
+			GVec d = gvec(lvl - 1);
 			if (lvl == top)
 				pass<KIND>(in, d, n, hgs, hgz, hrd);
 			else
-				pass<KIND>(GVec{sg + 2 * n}, d, n, hgs, hgz, hrd);
+				pass<KIND>(gvec(lvl), d, n, hgs, hgz, hrd);
 		}
 	}
 
@@ -463,17 +561,24 @@ struct Group {
 	static PDEV u32 ldE(const In &v, int t, u32) { return v.ld(t); }
 	static PDEV u32x4 ldE(const In &v, int t, u32x4) { return v.ld4(t); }
 	static PDEV u32x4 ldE(const AnySrc &v, int t, u32x4) { return v.ld4(t); }
+	// the same split by cache policy for the scratch vectors (hot: default, cold: non-temporal)
+	template <class A> static PDEV bool src_hot(const A &) { return false; }
+	static PDEV bool src_hot(const GVec &v) { return v.hot; }
+	template <class A, class E> static PDEV E ldH(const A &v, int t, E e) { return ldE(v, t, e); }
+	template <class A, class E> static PDEV E ldC(const A &v, int t, E e) { return ldE(v, t, e); }
+	static PDEV u32x4 ldH(const GVec &v, int t, u32x4) { return v.ld4h(t); }
+	static PDEV u32x4 ldC(const GVec &v, int t, u32x4) { return v.ld4c(t); }
 	PDEV void stE(int level, int t, u32 v) const
 	{
 		if (level > RL)
-			sg[(Q << level) + t] = v;
+			gregion(level)[t] = v;
 		else
 			sl[(Q << level) + t] = v;
 	}
 	PDEV void stE(int level, int t, u32x4 v) const
 	{
 		if (level > RL)
-			GVec{sg + (Q << level)}.st4(t, v);
+			gvec(level).st4(t, v);
 		else
 			LVec{sl + (Q << level)}.st4(t, v);
 	}
@@ -483,11 +588,21 @@ struct Group {
 	PDEV void chain_lane(const A &a, int lvl, u32 pad, const H *hs, const H *hz, u32 eb, int t, int nd, int step)
 	{
 		E x[U][1 << D];
+		if (src_hot(a)) { // one branch for the whole block of loads, not one per load
+			POLAR_KEEP_APART();
 #pragma unroll
-		for (int u = 0; u < U; ++u)
+			for (int u = 0; u < U; ++u)
 #pragma unroll
-			for (int j = 0; j < (1 << D); ++j)
-				x[u][j] = ldE(a, t + u * step + j * nd, E());
+				for (int j = 0; j < (1 << D); ++j)
+					x[u][j] = ldH(a, t + u * step + j * nd, E());
+			POLAR_KEEP_APART();
+		} else {
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+#pragma unroll
+				for (int j = 0; j < (1 << D); ++j)
+					x[u][j] = ldC(a, t + u * step + j * nd, E());
+		}
 #pragma unroll
 		for (int u = 0; u < U; ++u) {
 			const int tu = t + u * step;
@@ -521,7 +636,10 @@ struct Group {
 	{
 		int nd = Q << (lvl - D);
 		// loads in flight per lane from HBM: 16 x 16 bytes
-		const int U = (SrcIsLds<A>::value || D > 3) ? 1 : (16 >> D);
+#ifndef POLAR_INFLIGHT
+#define POLAR_INFLIGHT 16
+#endif
+		const int U = SrcIsLds<A>::value ? 1 : (POLAR_INFLIGHT >> D) > 0 ? (POLAR_INFLIGHT >> D) : 1;
 		if (U > 1 && nd >= 256 * U) {
 			PFOR_LANES(lane) {
 				for (int t = lane * 4; t < nd; t += 256 * U)
@@ -549,14 +667,14 @@ struct Group {
 			if (lvl == top)
 				chain_run<D, true>(in, lvl, pad, hls, hlz, eb);
 			else if (lvl > RL)
-				chain_run<D, true>(GVec{sg + (Q << lvl)}, lvl, pad, hls, hlz, eb);
+				chain_run<D, true>(gvec(lvl), lvl, pad, hls, hlz, eb);
 			else
 				chain_run<D, true>(LVec{sl + (Q << lvl)}, lvl, pad, hls, hlz, eb);
 		} else { // scratch planes: only reached when the child's zero plane is empty (chain())
 			if (lvl == top)
 				chain_run<D, false>(in, lvl, pad, hgs, hgz, hrd);
 			else
-				chain_run<D, false>(GVec{sg + (Q << lvl)}, lvl, pad, hgs, hgz, hrd);
+				chain_run<D, false>(gvec(lvl), lvl, pad, hgs, hgz, hrd);
 		}
 	}
 	PDEV void chain(int lvl, u32 hrd, u32 pad)
@@ -626,8 +744,9 @@ struct Group {
 	// d[t] = a[t] (op) b[t] over n plane dwords, 16-byte accesses with U of them in flight per
 	// array and lane once the arrays are long enough. MODE 0: copy b, 1: a ^ b, 2: a | b,
 	// 3: fill with zero. Returns "any result word nonzero" (wave-uniform).
+	// hot: default cache policy for the scratch accesses (planes of a hot level), else streaming
 	template <int MODE, class TD, class TA, class TB>
-	PDEV u32 plane_op(TD *d, const TA *a, const TB *b, int n)
+	PDEV u32 plane_op(TD *d, const TA *a, const TB *b, int n, bool hot = false)
 	{
 		u32 any = 0;
 		if (Q % 4 == 0 && n >= 256) {
@@ -641,9 +760,9 @@ struct Group {
 						int t = t0 + 256 * u;
 						if (t < n) {
 							if (MODE != 3)
-								y[u] = ldp4s(b + t);
+								y[u] = ldp4p(b + t, hot);
 							if (MODE == 1 || MODE == 2)
-								x[u] = ldp4s(a + t);
+								x[u] = ldp4p(a + t, hot);
 						}
 					}
 #pragma unroll
@@ -661,7 +780,7 @@ struct Group {
 								r.x = x[u].x | y[u].x; r.y = x[u].y | y[u].y; r.z = x[u].z | y[u].z; r.w = x[u].w | y[u].w;
 							}
 							acc |= r.x | r.y | r.z | r.w;
-							stp4s(d + t, r);
+							stp4p(d + t, r, hot);
 						}
 					}
 				}
@@ -699,18 +818,19 @@ struct Group {
 	{
 		int n = ((1 << (lvl - 1)) >> 3) * Q; // plane dwords per half; the left child starts the window
 		u32 *os = hgs + pidx(hrd, 0), *oz = hgz + pidx(hrd, 0);
+		const bool hot = is_hot(lvl);
 		if (RATE0)
-			plane_op<0>(os, hls, hls + n, n);
+			plane_op<0>(os, hls, hls + n, n, hot);
 		else
-			plane_op<1>(os, hls, hls + n, n);
-		plane_op<0>(os + n, hls, hls + n, n);
+			plane_op<1>(os, hls, hls + n, n, hot);
+		plane_op<0>(os + n, hls, hls + n, n, hot);
 		u32 any = RATE0 ? lds_any(hlz + n, n) : lds_any(hlz, 2 * n);
 		if (any) {
 			if (RATE0)
-				plane_op<0>(oz, hlz, hlz + n, n);
+				plane_op<0>(oz, hlz, hlz + n, n, hot);
 			else
-				plane_op<2>(oz, hlz, hlz + n, n);
-			plane_op<0>(oz + n, hlz, hlz + n, n);
+				plane_op<2>(oz, hlz, hlz + n, n, hot);
+			plane_op<0>(oz + n, hlz, hlz + n, n, hot);
 		}
 		set_zc(lvl, any);
 		wave_sync();
@@ -722,17 +842,18 @@ struct Group {
 		int n = ((1 << (lvl - 1)) >> 3) * Q;
 		u32 *ls = hgs + pidx(hrd, 0), *lz = hgz + pidx(hrd, 0);
 		u32 fl = RATE0 ? 0u : (zl >> (lvl - 1)) & 1u, fr = (zc >> (lvl - 1)) & 1u;
+		const bool hot = is_hot(lvl); // the result waits as long as the LLR vector of this level
 		if (RATE0)
-			plane_op<0>(ls, ls, ls + n, n);
+			plane_op<0>(ls, ls, ls + n, n, hot);
 		else
-			plane_op<1>(ls, ls, ls + n, n);
+			plane_op<1>(ls, ls, ls + n, n, hot);
 		if (fl | fr) {
 			if (!fr)
-				plane_op<3>(lz + n, lz, lz, n); // the right half becomes valid: no erasures there
+				plane_op<3>(lz + n, lz, lz, n, hot); // the right half becomes valid: no erasures there
 			else if (!fl)
-				plane_op<0>(lz, lz, lz + n, n); // left = 0 | right
+				plane_op<0>(lz, lz, lz + n, n, hot); // left = 0 | right
 			else
-				plane_op<2>(lz, lz, lz + n, n);
+				plane_op<2>(lz, lz, lz + n, n, hot);
 		}
 		set_zc(lvl, fl | fr);
 		wave_sync();

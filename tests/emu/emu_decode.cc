@@ -91,6 +91,14 @@ static int run(int8_t *msg, const int8_t *cw, const HostProgram &hp, size_t fram
 		g.hgs = planes.data();
 		g.hgz = planes.data() + nsoft / 8;
 		g.top = hp.top;
+		// two hot levels in a block of their own, as the kernel places them (decode_kernel.hpp)
+		g.hot_top = RL + 2 < hp.top ? RL + 2 : hp.top - 1;
+		g.sh = nullptr;
+		std::vector<u32x4> hot_;
+		if (g.hot_top > RL) {
+			hot_.assign((((size_t)Q << (g.hot_top + 1)) - ((size_t)Q << (RL + 1)) + 3) / 4, u32x4{0xDEADBEEF, 0xDEADBEEF, 0xDEADBEEF, 0xDEADBEEF});
+			g.sh = (u32 *)hot_.data() - ((size_t)Q << (RL + 1));
+		}
 		g.in = InVec<Q>{(const uint8_t *)pin.data() + g0, fp};
 		g.out = OutRows<Q>{(uint8_t *)pout.data() + g0, fp};
 		g.run(hp.ops.data());
