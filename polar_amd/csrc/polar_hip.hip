@@ -1225,6 +1225,8 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	if (lp.host.top > v->rl) { // LLR levels above the LDS levels and the partial-sum planes live in scratch
 		size_t soft = (size_t)v->q << lp.host.top;
 		block_dwords = soft + 2 * (soft / 8);
+		if (const char *e = getenv("POLAR_HIP_ARENA_PAD")) // experiments: dwords between the arenas (a multiple of 4)
+			block_dwords += (size_t)atoi(e) / 4 * 4;
 		if (!budget.fits(blocks * team * block_dwords * sizeof(u32))) { // fewer resident wavefronts, more sweeps
 			max_blocks = budget.limit() / (team * block_dwords * sizeof(u32));
 			if (max_blocks < 1)

@@ -121,12 +121,12 @@ PDEV u32 split_hi(u32 a) { return a & HI_MASK; }                 // bytes 1,3 st
 PDEV u32 split_lo(u32 a) { return perm(a, a, 0x020C000Cu); }     // bytes 0,2 -> high bytes, zero fill
 PDEV u32 merge(u32 hi, u32 lo) { return perm(hi, lo, 0x07030501u); } // high bytes -> b3=hi.3 b2=lo.3 b1=hi.1 b0=lo.1
 
-// prod (polar_helper.hh:153-160) on one 2xi16 register: sgn(x)sgn(y)min(|x|,|y|) = max(min(x,y), min(-x,-y));
-// the saturating negation maps -128 to +127 like vqabs.
+// prod (polar_helper.hh:153-160) on one 2xi16 register: sgn(x)sgn(y)min(|x|,|y|) = max(min(x,y), -max(x,y))
+// (the saturating negation is monotone non-increasing, so min(-x,-y) = -max(x,y) holds for -128 too, which
+// it maps to +127 like vqabs): four packed operations.
 PDEV u32 prod_half(u32 x, u32 y)
 {
-	u32 nx = pk_sub_sat(0, x), ny = pk_sub_sat(0, y);
-	return pk_max(pk_min(x, y), pk_min(nx, ny));
+	return pk_max(pk_min(x, y), pk_sub_sat(0, pk_max(x, y)));
 }
 PDEV u32 prod4(u32 a, u32 b)
 {
