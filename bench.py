@@ -70,6 +70,9 @@ def parse(argv=None):
     ap.add_argument("--include-extract", action="store_true", help="time re-encode + gather (testbench.cc:177-183) with every decode")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per thread (0 = skip)")
     ap.add_argument("--plumbing-only", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo test of the rank plumbing
+    ap.add_argument("--rank-timeout", type=float, default=1500.0, help="seconds the rank launcher waits for its children")
+    ap.add_argument("--init-timeout", type=float, default=180.0, help="seconds a rank waits in the process-group rendezvous")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)  # test: this rank exits 3 at start
     return ap.parse_args(argv)
 
 
@@ -78,41 +81,104 @@ def parse(argv=None):
 # ---------------------------------------------------------------------------------------
 
 def visible_gpus():
-    """Number of HIP devices, without initialising the runtime in this process."""
-    import torch
+    """Number of GPUs this process may use, WITHOUT touching HIP / HSA (the parent must not hold the
+    GPU when it starts its children): KFD topology nodes that have SIMDs, narrowed by the
+    *_VISIBLE_DEVICES variables. Returns None when the topology cannot be read (then every child
+    checks its own LOCAL_RANK against the runtime's count and exits non-zero if it has no GPU)."""
+    import glob
 
-    return torch.cuda.device_count()
+    nodes = 0
+    files = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not files:
+        return None
+    for f in files:
+        try:
+            for line in open(f):
+                k, _, v = line.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    nodes += 1
+        except (OSError, ValueError):
+            return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            nodes = min(nodes, len([x for x in v.split(",") if x.strip() != ""]))
+    return nodes
+
+
+def _tail(path, n=25):
+    try:
+        with open(path, "rb") as f:
+            return b"\n".join(f.read().splitlines()[-n:]).decode(errors="replace")
+    except OSError:
+        return ""
 
 
 def launch_ranks(args, argv):
-    """Start one child per GPU and relay rank 0's line. The parent never initialises HIP and
-    never replaces itself: children are ordinary subprocesses."""
+    """Start one child per GPU, relay rank 0's line. The parent never initialises HIP and never
+    replaces itself: children are ordinary subprocesses. All children are polled: the first one
+    that exits non-zero (or the deadline) ends the others, its stderr tail is printed and the
+    launcher returns non-zero -- a rank that dies before the rendezvous cannot leave the rest
+    waiting in it."""
+    import tempfile
+
     n = args.gpus
     if not args.plumbing_only:
         have = visible_gpus()
-        if have < n:
+        if have is not None and have < n:
             sys.stderr.write("bench.py: --gpus %d asked for but only %d GPU(s) are visible on this node\n" % (n, have))
             return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    tmp = tempfile.mkdtemp(prefix="bench_ranks_")
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
-    line, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(line.decode())
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(rcs) if c]
-    if bad:
-        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        out = open(os.path.join(tmp, "rank%d.out" % r), "wb")
+        err = open(os.path.join(tmp, "rank%d.err" % r), "wb")
+        logs.append((out, err))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out, stderr=err))
+    deadline = time.time() + args.rank_timeout
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(rcs) if c not in (None, 0)]
+        if bad:
+            failed = bad
+            break
+        if all(c == 0 for c in rcs):
+            break
+        if time.time() > deadline:
+            failed = [(r, "no exit after %.0f s" % args.rank_timeout) for r, c in enumerate(rcs) if c is None]
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 5
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    for out, err in logs:
+        out.close()
+        err.close()
+    if failed:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s; the other ranks were stopped\n" % failed)
+        for r, _ in failed:
+            sys.stderr.write("---- rank %d stderr (tail) ----\n%s\n" % (r, _tail(os.path.join(tmp, "rank%d.err" % r))))
         return 1
+    sys.stderr.write(_tail(os.path.join(tmp, "rank0.err"), 5) + "\n")
+    sys.stdout.write(open(os.path.join(tmp, "rank0.out")).read())
+    sys.stdout.flush()
     return 0
 
 
@@ -261,22 +327,27 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.fail_rank == rank:
+        sys.stderr.write("bench.py: rank %d fails on purpose (--fail-rank)\n" % rank)
+        sys.exit(3)
     import torch
 
     if args.plumbing_only:
         return plumbing_only(torch, args, rank, world)
     dist = None
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        raise SystemExit("bench.py needs a GPU: 0 GPU(s) are visible to rank %d and the HIP path has no CPU fallback" % rank)
     if torch.cuda.device_count() <= local:
-        raise SystemExit("bench.py: rank %d needs GPU %d but only %d are visible" % (rank, local, torch.cuda.device_count()))
+        raise SystemExit("bench.py: rank %d needs GPU %d but only %d GPU(s) are visible" % (rank, local, torch.cuda.device_count()))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        import datetime
+
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=args.init_timeout))
     import polar_amd
 
     M, systematic, default_frames = CONFIGS[args.config]
@@ -401,7 +472,9 @@ def plumbing_only(torch, args, rank, world):
     from polar_amd.shard import shard_range
 
     if world > 1:
-        dist.init_process_group("gloo")
+        import datetime
+
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.init_timeout))
     frames = args.frames or 1000
     a, b = shard_range(frames * world, rank, world)
     counters = torch.tensor([rank + 1, b - a, 0, 0], dtype=torch.int64)

@@ -114,6 +114,29 @@ def test_bench_launcher_refuses_missing_gpus():
     assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
 
 
+def test_bench_launcher_fails_fast_when_a_rank_dies():
+    """A rank that exits before the rendezvous must not leave the others (and the launcher) waiting
+    in it: the launcher stops the rest, prints the failing rank's stderr and returns non-zero."""
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--plumbing-only", "--fail-rank", "1",
+                        "--init-timeout", "600"], capture_output=True, text=True, timeout=120, env=env)
+    took = time.time() - t0
+    assert r.returncode != 0
+    assert "(1, 3)" in r.stderr and "fails on purpose" in r.stderr, r.stderr
+    assert took < 60, took  # far below the 600 s the surviving rank would wait in the rendezvous
+    # a launcher deadline ends ranks that never finish
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--plumbing-only", "--fail-rank", "1",
+                        "--rank-timeout", "0"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and time.time() - t0 < 60
+
+
 class _FakeSession:
     """Stands in for polar_amd.Session in the sweep harness tests: `simulate` reports one
     uncorrected error per frame below -1.0 dB (per 64 frames between -1.0 and -0.5 dB), none above."""
