@@ -107,11 +107,12 @@ def test_wide_variants_full_size_digest(session, oracle, golden, M, fpw, rl, tea
 
 @pytest.mark.parametrize("M,frames", [(16, 1 << 19), (16, (1 << 18) + 128 * 300 + 52), (16, 40000 + 21), (20, 4096 + 96)])
 def test_bench_grid_parity(session, oracle, golden, M, frames):
-    """The exact path bench.py times: default variant pick on a batch that fills every resident
-    wavefront for several sweeps (N = 2^16, 2^19 frames: (128, 6), >= 2048 persistent workgroups,
-    the XCD-aware group order, the multi-GiB scratch arena), and the team kernels the default pick
-    takes below that ((64, 7) and (32, 8) in teams of four) on sizes that are not a multiple of
-    the sweep or of a team. The
+    """The exact path bench.py times for config B: default variant pick on a batch that fills every
+    resident wavefront for several sweeps (N = 2^16, 2^19 frames: (128, 6), >= 2048 persistent
+    workgroups, the XCD-aware group order, the multi-GiB scratch arena, the hot region), and the team
+    kernels the default pick takes below that ((64, 7) and (32, 8) in teams of four) on sizes that
+    are not a multiple of the sweep or of a team; N = 2^20 with 4192 frames takes a narrow
+    single-wavefront shape (config D's own shape: test_config_d_shape_golden). The
     32 golden frames of the reference are tiled over the batch on the device: every 32-frame block
     of the output must equal block 0, and block 0 must hash to the reference's digest."""
     import polar_amd
@@ -139,6 +140,54 @@ def test_bench_grid_parity(session, oracle, golden, M, frames):
             assert bool((out[:, whole:] == out[:, :frames - whole]).all())
         assert "%016x" % fnv1a64(out[:, :32].contiguous().cpu().numpy()) == k["out_fnv"], (M, frames, k["family"])
     del out
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("mode", ["default-pick", "scratch-limited"])
+def test_config_d_shape_golden(session, oracle, golden, mode):
+    """Config D as bench.py runs it: N = 2^20 on the (32, 8) kernel in teams of four.
+    default-pick: a batch large enough for the default to take that shape (>= 3/8 of the resident
+    wavefronts get a group). scratch-limited: the same shape with so little free device memory that
+    the arenas of all resident wavefronts do not fit (launch_decode then runs fewer workgroups for
+    more sweeps) -- a ballast allocation takes the memory away. The reference's 32 golden frames are
+    tiled over the batch: every 32-frame block must equal block 0 and hash to the reference's digest."""
+    import polar_amd
+
+    meta, _ = golden
+    M = 20
+    N = 1 << M
+    fro = _code(oracle, M)
+    prog = oracle.compile(fro, M)
+    if mode == "scratch-limited":
+        session = polar_amd.Session(0)  # a handle of its own: no scratch held from earlier tests
+    dec = polar_amd.PolarDecoder(session)
+    k = [k for k in meta["decoder_digests"] if k["M"] == M][0]
+    cw = oracle.encode(pm1_message(k["msg_seed"], N // 2, k["frames"]), fro, M, 1)
+    llr = family_llr(k["family"], k["llr_seed"], cw)
+    frames = 24576 + 96 if mode == "default-pick" else 16384 + 128
+    d = torch.from_numpy(llr).cuda()
+    wide = d.repeat(1, (frames + 31) // 32)[:, :frames].contiguous()
+    del d
+    out = torch.full((N // 2, frames), 77, dtype=torch.int8, device="cuda")
+    ballast = None
+    try:
+        if mode == "scratch-limited":
+            session.configure(32, 8, 0, 4)
+            free, _total = torch.cuda.mem_get_info()
+            # leave ~12 GiB free: 5/8 of it holds 48 of the 40 MiB arenas, 129 teams then take 3 sweeps
+            ballast = torch.empty(max(0, free - (12 << 30)), dtype=torch.uint8, device="cuda")
+        dec(out, wide, prog)
+        shape = session.last_decode_shape()
+        assert tuple(shape) == (32, 8, 4), shape
+    finally:
+        del ballast
+        session.configure(0, 0, 0)
+    del wide
+    whole = frames // 32 * 32
+    blocks = out[:, :whole].view(N // 2, whole // 32, 32)
+    assert bool((blocks == blocks[:, :1, :]).all()), mode
+    assert "%016x" % fnv1a64(out[:, :32].contiguous().cpu().numpy()) == k["out_fnv"], mode
+    del out, blocks
     torch.cuda.empty_cache()
 
 
