@@ -31,8 +31,8 @@ times the reference's own AVX2 decoder (oracle/_ref, built from the reference he
 host cores for a bounded sample of the same LLRs.
 
 Other configs of BASELINE.json (`--config`): A = N=2^10 non-systematic (configs[0]), D = N=2^20
-systematic (configs[3]); B (default) is the headline. They change the workload named in
-`config.workload`, nothing else.
+systematic (configs[3]), E = mixed N=2^10..2^16 with per-SNR frozen sets (configs[4]); B (default)
+is the headline. They change the workload named in `config.workload`, nothing else.
 """
 import argparse
 import json
@@ -55,7 +55,12 @@ CONFIGS = {
     "A": (10, 0, 1 << 22),
     "B": (16, 1, 1 << 20),
     "D": (20, 1, 1 << 16),
+    # E: BASELINE configs[4] -- one launch set mixing N = 2^10 .. 2^16, every (N, channel SNR) with the frozen
+    # set designed for that SNR (testbench.cc:74-88 per point); "frames" = bytes of LLRs per (N, SNR) batch
+    "E": (0, 1, 1 << 29),
 }
+E_LEVELS = range(10, 17)
+E_SNRS = (-2.0, -1.5, -1.0, -0.5)
 
 
 def parse(argv=None):
@@ -195,7 +200,7 @@ def make_code(polar_amd, M):
     return fro, prog[:n].copy()
 
 
-def generate(torch, polar_amd, sess, fro, M, systematic, frames, seed, first_frame, dev):
+def generate(torch, polar_amd, sess, fro, M, systematic, frames, seed, first_frame, dev, snr_db=SNR_DB):
     """Resident batch: llr [N][frames] int8 and the decoder-domain (u) truth [K][frames].
     Message bits and noise come from the library's counter-based source (polar_hip_random_message,
     polar_hip_channel): global frame g is the same whatever rank or chunk produces it."""
@@ -214,7 +219,7 @@ def generate(torch, polar_amd, sess, fro, M, systematic, frames, seed, first_fra
         cw = torch.empty((N, c), dtype=torch.int8, device=dev)
         enc(cw, msg, fro)
         q = torch.empty((N, c), dtype=torch.int8, device=dev)
-        sess.channel(q, cw, SNR_DB, seed, first_frame + a)
+        sess.channel(q, cw, snr_db, seed, first_frame + a)
         sess.count(stats, q, cw, None, None)  # awgn_errors / quantization_erasures of the batch
         llr[:, a:a + c] = q
         if systematic:
@@ -256,10 +261,12 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(llr_sample, prog, K, seconds):
+def cpu_baseline(jobs, seconds):
     """The genuine reference decoder (PolarDecoder<SIMD<int8_t,32>>) on the host cores. The GPU
     box gives a 1-GPU job a share of 16 CPUs (OMP_NUM_THREADS there), so 16 threads are used
-    even though os.cpu_count() reports the whole machine."""
+    even though os.cpu_count() reports the whole machine. jobs: [(llr_sample, prog, K)], one per
+    code of the workload (one for configs A / B / D); every thread decodes bundles of every code,
+    the time budget split evenly between the codes."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
 
@@ -270,23 +277,25 @@ def cpu_baseline(llr_sample, prog, K, seconds):
         W = ref.width
         kind = "reference"
 
-        def timed(bundle, reps):
+        def timed(bundle, prog, reps):
             return ref.decode_time(bundle, prog, reps)
     else:
         orc = oracle_lib.Oracle()
         W = 32
         kind = "port"
 
-        def timed(bundle, reps):
+        def timed(bundle, prog, reps):
             return orc.decode_time(bundle, prog, reps)
-    have = llr_sample.shape[1] // W
-    bundles = [np.ascontiguousarray(llr_sample[:, (t % have) * W:(t % have + 1) * W]) for t in range(threads)]
-    per_call = timed(bundles[0], 3) / 3
-    reps = max(1, int(seconds / per_call))
+    plan = []  # per code: (bundles per thread, prog, K, reps)
+    for llr_sample, prog, K in jobs:
+        have = llr_sample.shape[1] // W
+        bundles = [np.ascontiguousarray(llr_sample[:, (t % have) * W:(t % have + 1) * W]) for t in range(threads)]
+        per_call = timed(bundles[0], prog, 3) / 3
+        plan.append((bundles, prog, K, max(1, int(seconds / len(jobs) / per_call))))
     out = [0.0] * threads
 
     def work(t):
-        out[t] = timed(bundles[t], reps)
+        out[t] = sum(timed(bundles[t], prog, reps) for bundles, prog, _K, reps in plan)
 
     th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
     t0 = time.time()
@@ -295,24 +304,46 @@ def cpu_baseline(llr_sample, prog, K, seconds):
     for x in th:
         x.join()
     wall = time.time() - t0
-    bits = threads * reps * W * K
+    bits = threads * sum(reps * W * K for _b, _p, K, reps in plan)
+    calls = sum(reps for _b, _p, _K, reps in plan)
     return {
         "value": bits / max(out) / 1e9, "unit": "Gbit/s", "cores": threads, "kind": kind,
         "host_cpus_visible": os.cpu_count(), "cpu_model": cpu_model(),
-        "sample": "%d threads x %d calls x %d frames of the same LLR batch, decode only (wall %.1f s, %.1f us per call); threads = the job's CPU share, not the machine's %s CPUs" % (
-            threads, reps, W, wall, 1e6 * max(out) / reps, os.cpu_count()),
+        "sample": "%d threads x %d calls x %d frames over %d code(s) of the workload, the same LLR bundle per code and thread, decode only (wall %.1f s, %.1f us per call); threads = the job's CPU share, not the machine's %s CPUs" % (
+            threads, calls, W, len(jobs), wall, 1e6 * max(out) / calls, os.cpu_count()),
     }
 
 
+def _file_sha16(path):
+    import hashlib
+
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+def library_sha16():
+    """Identity of the kernel code the counters were (or are) taken on: the decode-kernel sources."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("sc_core.hpp", "decode_kernel.hpp", "variants.hip", "program.hpp", "polar_hip.hip"):
+        h.update(open(os.path.join(ROOT, "polar_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_profile_counters(frames, args):
-    """HBM bytes and VALU / LDS utilisation of the decode kernel from the committed rocprofv3
-    PMC passes of this same command (tools/prof_bench.sh -> profiles/hbm_traffic.json)."""
+    """HBM bytes and VALU / LDS utilisation of the decode kernel from the committed rocprofv3 PMC
+    passes of this same command (tools/prof_bench.sh -> profiles/hbm_traffic*.json). These are NOT
+    measured in this run: the record says which file they come from and on which kernel sources
+    they were taken (`kernel_sources_sha16`); when the sources have changed since, the figures are
+    dropped from the line and `stale` is set instead."""
     for name in ("hbm_traffic.json", "hbm_traffic_%s.json" % args.config):
         tpath = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tpath):
             continue
         t = json.load(open(tpath))
         if t.get("frames") == frames and t.get("fpw") == args.fpw and t.get("lds_level") == args.lds_level and t.get("config", "B") == args.config and "bytes_per_launch" in t:
+            t["_file"] = "profiles/" + name
+            t["_stale"] = t.get("kernel_sources_sha16") != library_sha16()
             return t
     return None
 
@@ -351,12 +382,17 @@ def main():
     import polar_amd
 
     M, systematic, default_frames = CONFIGS[args.config]
-    N = 1 << M
-    K = N // 2
-    frames = args.frames or default_frames
     sess = polar_amd.Session(local)
     if args.fpw:
         sess.configure(args.fpw, args.lds_level, 0)
+    if args.config == "E":
+        run_config_e(torch, polar_amd, sess, args, rank, world, dev, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    N = 1 << M
+    K = N // 2
+    frames = args.frames or default_frames
     fro, prog = make_code(polar_amd, M)
     seed, first = 42, rank * frames
     llr, u_true, chan = generate(torch, polar_amd, sess, fro, M, systematic, frames, seed, first, dev)
@@ -422,6 +458,10 @@ def main():
         alg = frames * 1.5 * N
         achieved = alg / (k_ms * 1e-3) / 1e9
         prof = load_profile_counters(frames, args)
+        if prof and prof["_stale"]:
+            stale, prof = prof, None
+        else:
+            stale = None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": prof.get("bytes_per_launch") if prof else None,
                 "kernel": ("sc_decode_team_kernel<%d, %d, %d>" % (shape[0] // 4, shape[1], shape[2])) if shape[2] > 1 else "sc_decode_kernel<%d, %d>" % (shape[0] // 4, shape[1]),
@@ -434,6 +474,12 @@ def main():
             for key in ("valu_util", "lds_bw_util", "lds_bank_conflict_frac"):
                 if key in prof:
                     roof[key] = prof[key]
+            roof["counters_from"] = {"file": prof["_file"], "kernel_sources_sha16": prof.get("kernel_sources_sha16"),
+                                     "note": "rocprofv3 --pmc passes of this command (tools/prof_bench.sh), committed; not measured in this run"}
+        elif stale:
+            roof["counters_from"] = {"file": stale["_file"], "stale": True, "kernel_sources_sha16": stale.get("kernel_sources_sha16"),
+                                     "current_sources_sha16": library_sha16(),
+                                     "note": "the committed counters were taken on other kernel sources: traffic / VALU / LDS figures left out"}
         what = "SC decode of the batch (what testbench.cc:170-174 times)"
         if args.include_extract:
             what += " + fused re-encode/gather (testbench.cc:177-183)"
@@ -457,10 +503,127 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0:
             sample = llr[:, :16 * 32].cpu().numpy() if M <= 16 else llr[:, :32].cpu().numpy()
-            line["cpu_baseline"] = cpu_baseline(sample, prog, K, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline([(sample, prog, K)], args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def run_config_e(torch, polar_amd, sess, args, rank, world, dev, dist):
+    """BASELINE configs[4]: one launch set that mixes N = 2^10 .. 2^16, every (N, channel SNR) batch with
+    the frozen set PolarCodeConst0 designs for that very SNR (testbench.cc:74-88 evaluated per point,
+    through the handle's (level, K, p) cache: construction, compilation and upload happen once per
+    key). Every batch holds the same number of LLR bytes, so small codes bring many frames and the
+    largest code few (the small-batch regime of the decoder). One step = the decode of all batches,
+    back to back; `value` = information bits of all of them / wall time."""
+    from polar_amd.sweep import design_probability
+
+    batch_bytes = args.frames or CONFIGS["E"][2]
+    seed = 42
+    jobs = []
+    t_code = time.perf_counter()
+    for M in E_LEVELS:
+        N = 1 << M
+        for si, snr in enumerate(E_SNRS):
+            fro, prog, _amb = sess.code(M, N // 2, design_probability(snr))
+            jobs.append({"M": M, "snr": snr, "fro": fro, "prog": prog, "frames": max(32, batch_bytes // N), "si": si})
+    t_code = time.perf_counter() - t_code
+    chan = torch.zeros(4, dtype=torch.int64, device=dev)
+    for j in jobs:
+        # frames of different (N, SNR) batches never share a counter-based stream: the frame index space is split per job
+        first = (jobs.index(j) * world + rank) * (1 << 24)
+        j["llr"], j["u"], st = generate(torch, polar_amd, sess, j["fro"], j["M"], 1, j["frames"], seed, first, dev, j["snr"])
+        j["out"] = torch.empty(((1 << j["M"]) // 2, j["frames"]), dtype=torch.int8, device=dev)
+        chan += st
+    dec = polar_amd.PolarDecoder(sess)
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+    kernel_ms, shapes = [], {}
+
+    def step():
+        total = 0.0
+        for j in jobs:
+            dec(j["out"], j["llr"], j["prog"])
+            total += sess.last_decode_ms()
+            shapes[j["M"]] = sess.last_decode_shape()
+        kernel_ms.append(total)
+
+    def tally():
+        counters.zero_()
+        for j in jobs:
+            sess.count(counters, None, None, j["out"], j["u"])
+        if dist is not None:
+            dist.all_reduce(counters)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    tally()
+    kernel_ms.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    tally()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.all_reduce(chan)
+    c = counters.cpu().tolist()
+    ch = chan.cpu().tolist()
+    info_bits = sum(j["frames"] * (1 << j["M"]) // 2 for j in jobs)
+    value = info_bits * world * args.steps / elapsed / 1e9
+    if rank != 0:
+        return
+    k_ms = float(np.mean(kernel_ms))
+    alg = sum(j["frames"] * 1.5 * (1 << j["M"]) for j in jobs)
+    achieved = alg / (k_ms * 1e-3) / 1e9
+    prof = load_profile_counters(batch_bytes, args)
+    stale = None
+    if prof and prof["_stale"]:
+        stale, prof = prof, None
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": prof.get("bytes_per_launch") if prof else None,
+            "kernel": "sc_decode kernels, one launch per batch; shape (frames per wavefront, LDS level, team) by N: " + ", ".join(
+                "2^%d: %s" % (M, tuple(shapes[M])) for M in sorted(shapes)),
+            "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
+            "note": "one 'launch' here = the %d decode launches of a step; kernel_ms and traffic are their sums" % len(jobs)}
+    if prof:
+        roof["traffic_frac"] = prof["bytes_per_launch"] / (k_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
+        for key in ("valu_util", "lds_bw_util", "lds_bank_conflict_frac"):
+            if key in prof:
+                roof[key] = prof[key]
+        roof["counters_from"] = {"file": prof["_file"], "kernel_sources_sha16": prof.get("kernel_sources_sha16"),
+                                 "note": "rocprofv3 --pmc passes of this command (tools/prof_bench.sh), committed; not measured in this run"}
+    elif stale:
+        roof["counters_from"] = {"file": stale["_file"], "stale": True, "note": "taken on other kernel sources: figures left out"}
+    line = {
+        "metric": "decoded info Gbit/s (node), mixed N=2^10..2^16 R=1/2 int8 SC with per-SNR frozen sets", "value": value, "unit": "Gbit/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+        "config": {
+            "workload": "config E: %d resident batches per GPU = N in 2^10..2^16 x channel Es/N0 in %s dB, each with the systematic Const0 code designed for its own SNR (per-SNR frozen set and program from the handle's cache), %d MiB of int8 LLRs per batch (%d .. %d frames); step = SC decode of every batch, back to back; the timed region ends with one error count%s" % (
+                len(jobs), list(E_SNRS), batch_bytes >> 20, jobs[-1]["frames"], jobs[0]["frames"], " + RCCL all-reduce of the counters" if world > 1 else ""),
+            "batches_per_gpu": len(jobs), "batch_bytes": batch_bytes, "parallelism": "frames sharded over %d GPU(s)" % world,
+            "shape_chosen_by": "caller" if args.fpw else "library default",
+            "code_construction_s": t_code,
+        },
+        "roofline": roof,
+        "frac_of_hbm_roofline_whole_job": value * 1e9 * 3 / (HBM_PEAK_GBS * 1e9 * world),
+        "ber_u_domain": c[2] / float(info_bits * world), "uncorrected_errors_u_domain": c[2], "ambiguity_erasures": c[3],
+        "awgn_errors": ch[0], "quantization_erasures": ch[1],
+    }
+    if world == 1 and args.cpu_seconds > 0:
+        sample = [(j["llr"][:, :64].cpu().numpy(), j["prog"], (1 << j["M"]) // 2) for j in jobs if j["si"] == len(E_SNRS) // 2]
+        line["cpu_baseline"] = cpu_baseline(sample, args.cpu_seconds)
+    print(json.dumps(line), flush=True)
 
 
 def plumbing_only(torch, args, rank, world):

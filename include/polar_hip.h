@@ -155,8 +155,9 @@ int polar_hip_decode_f32(polar_hip_handle *h, int program_id, float *message, co
  *   - frames must be a multiple of 32 and both pointers 16-byte aligned (no staging copies);
  *     a multiple of 128 runs the faster team kernel (four wavefronts per workgroup) when four
  *     arenas fit the array together, anything else one wavefront per workgroup;
- *   - one wavefront's arena, 10 * 2^level bytes, must fit the array: codes up to N = 2^22;
- *     the array bounds the resident wavefronts (25 at N = 2^16), so big codes decode slowly here;
+ *   - one wavefront's arena, 40 * 2^level bytes (32 frames: LLR levels + two partial-sum planes),
+ *     must fit the array: codes up to N = 2^20; the array bounds the resident wavefronts (25 at
+ *     N = 2^16), so big codes decode slowly here;
  *   - the program must have been loaded with polar_hip_load_program (its instruction stream for
  *     this entry point's kernel shape is uploaded then).
  * Every call on one GPU shares that GPU's array: calls that overlap on one GPU race (also across

@@ -834,7 +834,11 @@ static int upload_shape(LoadedProgram &lp, const KernelVariant *v)
 	DevOp *d = nullptr;
 	size_t bytes = hp.ops.size() * sizeof(DevOp);
 	HIP_TRY(hipMalloc((void **)&d, bytes));
-	HIP_TRY(hipMemcpy(d, hp.ops.data(), bytes, hipMemcpyHostToDevice));
+	hipError_t e = hipMemcpy(d, hp.ops.data(), bytes, hipMemcpyHostToDevice);
+	if (e != hipSuccess) {
+		(void)hipFree(d);
+		HIP_TRY(e);
+	}
 	lp.dev[shape] = d;
 	return POLAR_OK;
 }
@@ -935,21 +939,33 @@ extern "C" int polar_hip_create(polar_hip_handle **out, int device)
 	polar_hip_handle *h = new polar_hip_handle;
 	h->device = device;
 	h->cus = prop.multiProcessorCount;
-	HIP_TRY(hipSetDevice(device));
-	HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
-	h->stream = h->own_stream;
-	HIP_TRY(hipEventCreate(&h->ev0));
-	HIP_TRY(hipEventCreate(&h->ev1));
-	if (device < MAX_DEVICES && !g_static_scratch[device]) { // once per device, with that device current
-		void *ptr = nullptr;
-		HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
-		g_static_scratch[device] = ptr;
-	}
-	for (int team : {1, (int)STATIC_TEAM}) { // the static entry point must not meet a first-use query: resident workgroups of its kernel shapes, now
-		const KernelVariant *sv = find_variant(STATIC_Q, STATIC_RL, team);
-		int per_cu = 0;
-		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sv->fn, 64 * team, 0));
-		h->occupancy[(const void *)sv->fn] = per_cu;
+	auto init = [&]() -> int {
+		HIP_TRY(hipSetDevice(device));
+		HIP_TRY(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+		h->stream = h->own_stream;
+		HIP_TRY(hipEventCreate(&h->ev0));
+		HIP_TRY(hipEventCreate(&h->ev1));
+		if (device < MAX_DEVICES && !g_static_scratch[device]) { // once per device, with that device current
+			void *ptr = nullptr;
+			HIP_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+			g_static_scratch[device] = ptr;
+		}
+		for (int team : {1, (int)STATIC_TEAM}) { // the static entry point must not meet a first-use query: resident workgroups of its kernel shapes, now
+			const KernelVariant *sv = find_variant(STATIC_Q, STATIC_RL, team);
+			if (!sv)
+				return fail(POLAR_E_HIP, "polar_hip_create: the kernel shape of polar_hip_decode_static is not built into this library");
+			int per_cu = 0;
+			HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sv->fn, 64 * team, 0));
+			h->occupancy[(const void *)sv->fn] = per_cu;
+		}
+		return POLAR_OK;
+	};
+	int rc = init();
+	if (rc) { // nothing of a half-made handle is left behind (the error text is kept)
+		std::string keep = g_error;
+		polar_hip_destroy(h);
+		g_error = keep;
+		return rc;
 	}
 	*out = h;
 	return POLAR_OK;
@@ -1604,6 +1620,8 @@ extern "C" int polar_hip_decode_static(polar_hip_handle *h, int program_id, int8
 	const bool teams = frames % (fpw * STATIC_TEAM) == 0 &&
 		(lp.host.top <= STATIC_RL || STATIC_SCRATCH_BYTES / (scratch_bytes_per_wave(STATIC_Q, lp.host.top) * STATIC_TEAM) >= 1);
 	const KernelVariant *v = find_variant(STATIC_Q, STATIC_RL, teams ? STATIC_TEAM : 1);
+	if (!v)
+		return fail(POLAR_E_HIP, "polar_hip_decode_static: kernel shape not built into this library");
 	const size_t team = (size_t)v->team;
 	if (frames % fpw || (uintptr_t)codeword % 16 || (uintptr_t)message % 16)
 		return fail(POLAR_E_ARG, "polar_hip_decode_static: frames must be a multiple of 32 and both buffers 16-byte aligned (this entry point cannot stage ragged batches: it does not allocate)");

@@ -15,6 +15,8 @@ What differs from the reference, on purpose:
 """
 import math
 import sys
+import threading
+import time
 
 import numpy as np
 
@@ -29,6 +31,19 @@ def design_snr(rate=0.5):
 def design_probability(snr_db):
     """testbench.cc:85-87: erasure probability PolarCodeConst0 is fed for a design SNR."""
     return math.exp(-(10.0 ** ((snr_db + 1.59175) / 10.0)))
+
+
+def host_code(M, K, p):
+    """(frozen, program) of PolarCodeConst0(M, K, p) + PolarCompiler on the host, no device handle
+    involved (polar_freezer.hh:34-62, polar_compiler.hh:51-58 through the C ABI's host functions)."""
+    from . import PolarCodeConst0, PolarCompiler
+
+    N = 1 << M
+    fro = np.zeros(N, np.uint8)
+    PolarCodeConst0()(fro, M, K, p)
+    prog = np.zeros(2 * N + 1, np.uint8)
+    n = PolarCompiler()(prog, fro, M)
+    return fro, prog[:n].copy()
 
 
 def snr_points(design):
@@ -59,11 +74,39 @@ def ber_sweep(session, M, systematic=True, rate=0.5, seed=42, chunk=1 << 14, max
             N, K, "systematic" if systematic else "non-systematic", design, " (tie at the K boundary)" if amb else "", world, max_frames, chunk), file=out)
         print("# SNR BER Mbit/s Eb/N0", file=out)
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu"))
-    for idx, snr in enumerate(snr_points(design)):
+    # per-SNR design: PolarCodeConst0 + PolarCompiler are host work (long double, the
+    # reference's own arithmetic). The code of point i+1 is constructed on a host thread while point
+    # i decodes on the device; only its upload (polar_hip_load_program, inside simulate) stays on the
+    # calling thread, because the handle is not thread-safe. t_wait = what the sweep still waits for.
+    t_start, t_wait, t_build = time.perf_counter(), 0.0, [0.0]
+    points = list(snr_points(design))
+    pending = None
+
+    def build(snr):
+        t0 = time.perf_counter()
+        r = host_code(M, K, design_probability(snr))
+        t_build[0] += time.perf_counter() - t0
+        return r
+
+    def prefetch(i):
+        if not per_snr_design or i >= len(points):
+            return None
+        box = {}
+        th = threading.Thread(target=lambda: box.update(code=build(points[i])))
+        th.start()
+        return th, box
+
+    if per_snr_design:
+        pending = prefetch(0)
+    for idx, snr in enumerate(points):
         if count > clean_points:
             break
         if per_snr_design:
-            fro, prog, _ = session.code(M, K, design_probability(snr))
+            t0 = time.perf_counter()
+            pending[0].join()
+            fro, prog = pending[1]["code"]
+            t_wait += time.perf_counter() - t0
+            pending = prefetch(idx + 1)
         total = torch.zeros(6, dtype=torch.int64, device=dev)
         done, ms, bits = 0, 0.0, 0.0
         while done < max_frames:
@@ -95,6 +138,12 @@ def ber_sweep(session, M, systematic=True, rate=0.5, seed=42, chunk=1 << 14, max
         if rank == 0:
             print("%g %g %g %g" % (snr, ber, mbs, ebn0), file=out, flush=True)
         count += 1
+    if pending is not None:
+        pending[0].join()
     if rank == 0:
         print("# QEF at: %s SNR, speed: %g Mb/s." % ("%g" % min_snr if min_snr is not None else "none", max_mbs), file=out, flush=True)
+        if per_snr_design:
+            wall = time.perf_counter() - t_start
+            print("# per-SNR code construction + compilation on the host: %.3f s in all, %.3f s of them waited for (the rest ran beside the previous point's decode); sweep wall %.3f s -> %.2f %% of it" % (
+                t_build[0], t_wait, wall, 100.0 * t_wait / wall if wall > 0 else 0.0), file=out, flush=True)
     return rows

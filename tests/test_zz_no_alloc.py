@@ -1,7 +1,7 @@
 """polar_hip_decode_static (include/polar_hip.h): the entry point that allocates nothing, called
-through the C ABI and compared bit for bit with polar_hip_decode on the same inputs -- two calls in
-a row, the second with a smaller input (stale scratch of the first call must not leak), codes
-above and below the LDS levels, and the documented rejections."""
+through the C ABI and compared bit for bit with the oracle (and with polar_hip_decode) on the same
+inputs -- two calls in a row, the second with a smaller input (stale scratch of the first call must
+not leak), codes above and below the LDS levels, and the documented rejections."""
 import ctypes
 
 import numpy as np
@@ -22,7 +22,8 @@ def _pair(session, oracle, M, frames, fam, seed):
     prog = oracle.compile(fro, M)
     pid, rows = session.load_program(prog)
     cw = oracle.encode(pm1_message(seed, N // 2, frames), fro, M, 0)
-    llr = torch.from_numpy(family_llr(fam, seed + 1, cw)).cuda()
+    host = family_llr(fam, seed + 1, cw)
+    llr = torch.from_numpy(host).cuda()
     ref = torch.full((rows, frames), 55, dtype=torch.int8, device="cuda")
     got = torch.full((rows, frames), 66, dtype=torch.int8, device="cuda")
     torch.cuda.synchronize()
@@ -32,6 +33,7 @@ def _pair(session, oracle, M, frames, fam, seed):
     assert rc == 0, lib.polar_hip_last_error()
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] == free_before  # nothing was allocated on the device
+    assert (got.cpu().numpy() == oracle.decode(host, prog)).all(), (M, frames, fam)  # the oracle, not only HIP against HIP
     return ref, got
 
 
@@ -67,12 +69,22 @@ def test_static_entry_point_rejections(session, oracle):
     assert rc == -1 and b"multiple of 32" in lib.polar_hip_last_error()
     rc = lib.polar_hip_decode_static(session._h, pid + 1000, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(llr.data_ptr()), 32, ctypes.c_void_p(0))
     assert rc == -1
-    # N = 2^23 would need an 80 MiB arena per wavefront: beyond the 64 MiB array
-    big = np.array([23, 3, 255], np.uint8)  # rate-0 code of level 23: decodes nothing, but its arena is sized by the level
-    pid2 = lib.polar_hip_load_program(session._h, big.ctypes.data, big.size)
-    if pid2 >= 0:
-        rc = lib.polar_hip_decode_static(session._h, pid2, None, ctypes.c_void_p(llr.data_ptr()), 32, ctypes.c_void_p(0))
-        assert rc == -1 and b"static array" in lib.polar_hip_last_error()
+    # one wavefront's arena is 40 * 2^level bytes (32 frames, LLR levels + two planes): N = 2^20 needs
+    # 40 MiB and is accepted, N = 2^21 needs 80 MiB, beyond the 64 MiB array. Rate-0 codes: they decode
+    # nothing, but the arena is sized by the level.
+    tiny = torch.zeros(32, dtype=torch.int8, device="cuda")
+    for level, ok in ((20, True), (21, False)):
+        big = np.array([level, 3, 255], np.uint8)
+        pid2 = lib.polar_hip_load_program(session._h, big.ctypes.data, big.size)
+        assert pid2 >= 0, lib.polar_hip_last_error()
+        wide = torch.zeros((1 << level, 32), dtype=torch.int8, device="cuda")
+        rc = lib.polar_hip_decode_static(session._h, pid2, ctypes.c_void_p(tiny.data_ptr()), ctypes.c_void_p(wide.data_ptr()), 32, ctypes.c_void_p(0))
+        torch.cuda.synchronize()
+        if ok:
+            assert rc == 0, lib.polar_hip_last_error()
+        else:
+            assert rc == -1 and b"static array" in lib.polar_hip_last_error()
+        del wide
 
 
 def test_static_entry_point_in_a_hip_graph(session, oracle):

@@ -19,8 +19,8 @@ def opt(name, default, conv=int):
 
 
 config = opt("--config", "B", str)
-M = {"A": 10, "B": 16, "D": 20}[config]
-frames = opt("--frames", {"A": 1 << 22, "B": 1 << 20, "D": 1 << 16}[config])
+M = {"A": 10, "B": 16, "D": 20, "E": 0}[config]
+frames = opt("--frames", {"A": 1 << 22, "B": 1 << 20, "D": 1 << 16, "E": 1 << 29}[config])
 fpw, rl = opt("--fpw", 0), opt("--lds-level", 0)
 kernel_ns = None
 for row in csv.DictReader(open(os.path.join(out, "kernel_stats.csv"))):
@@ -35,7 +35,10 @@ for k, v in sorted(vals.items()):
     big = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v
     res[k] = sum(big) / len(big)
     print("%-22s %d decode dispatches, %d batch-sized, mean %.6g" % (k, len(v), len(big), res[k]))
-doc = {"config": config, "frames": frames, "fpw": fpw, "lds_level": rl,
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # library_sha16(): the kernel sources these counters are taken on
+
+doc = {"config": config, "frames": frames, "fpw": fpw, "lds_level": rl, "kernel_sources_sha16": bench.library_sha16(),
        "source": "rocprofv3 --pmc, one counter group per run of the same bench command (tools/prof_bench.sh); FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled per MI355X_MICROARCH.md"}
 if "FETCH_SIZE" in res and "WRITE_SIZE" in res:
     rd, wr = 2 * res["FETCH_SIZE"] * 1024, res["WRITE_SIZE"] * 1024
