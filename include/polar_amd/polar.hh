@@ -8,8 +8,9 @@
 //   PolarFreezer::operator()(uint8_t *frozen, int level, long double p = 0.5L, long double th = 0.5L) -> K   polar_freezer.hh:23
 //   PolarCodeConst0<MAX_M>::operator()(uint8_t *frozen, int level, int K, long double p = exp(-1.L))  polar_freezer.hh:49
 //
-// TYPE = GPU<int8_t, W>: a lane bundle of W frames, laid out exactly like the reference's
-// SIMD<int8_t, W> (W consecutive bytes = one code element of W frames, testbench.cc:134-139),
+// TYPE = GPU<int8_t, W> or GPU<float, W> (the bench's code_type, testbench.cc:49-53): a lane bundle
+// of W frames, laid out exactly like the reference's SIMD<VALUE, W> (W consecutive values = one code
+// element of W frames, testbench.cc:134-139),
 // so caller code that sizes and casts buffers with sizeof(TYPE) keeps working; W is no longer
 // limited by a vector register (thousands to millions of frames per call). The buffers of one call
 // may be host memory (as in the reference) or device memory (hipMalloc): polar_hip_where() tells.
@@ -39,6 +40,34 @@ inline void check(int rc, const char *what)
 		fprintf(stderr, "%s failed (%d): %s\n", what, rc, polar_hip_last_error());
 		abort();
 	}
+}
+// both buffers of one call must live on the same side (the C ABI takes one `where`): a device
+// codeword with a host message would hand the kernel a host pointer
+inline int where_of(const void *a, const void *b, const char *what)
+{
+	int wa = polar_hip_where(a), wb = polar_hip_where(b);
+	if (a && b && wa != wb) {
+		fprintf(stderr, "%s: message and codeword must both be host or both be device memory\n", what);
+		abort();
+	}
+	return a ? wa : wb;
+}
+// element types of the lane bundles: int8_t (the bench default) and float (testbench.cc:49-53)
+inline int encode(polar_hip_handle *h, int sys, int8_t *cw, const int8_t *msg, const uint8_t *frozen, int level, size_t frames, int where)
+{
+	return polar_hip_encode(h, sys, cw, msg, frozen, level, frames, where);
+}
+inline int encode(polar_hip_handle *h, int sys, float *cw, const float *msg, const uint8_t *frozen, int level, size_t frames, int where)
+{
+	return polar_hip_encode_f32(h, sys, cw, msg, frozen, level, frames, where);
+}
+inline int decode(polar_hip_handle *h, int id, int8_t *msg, const int8_t *cw, size_t frames, int where)
+{
+	return polar_hip_decode(h, id, msg, cw, frames, where);
+}
+inline int decode(polar_hip_handle *h, int id, float *msg, const float *cw, size_t frames, int where)
+{
+	return polar_hip_decode_f32(h, id, msg, cw, frames, where);
 }
 // one device context per host thread, created on first use (device from POLAR_HIP_DEVICE)
 inline polar_hip_handle *context()
@@ -93,25 +122,27 @@ class PolarSysEnc;
 template <typename TYPE, int MAX_M>
 class PolarDecoder;
 
-template <int W, int M>
-class PolarEncoder<GPU<int8_t, W>, M>
+template <typename VALUE, int W, int M>
+class PolarEncoder<GPU<VALUE, W>, M>
 {
-	typedef GPU<int8_t, W> TYPE;
+	typedef GPU<VALUE, W> TYPE;
 public:
 	void operator()(TYPE *codeword, const TYPE *message, const uint8_t *frozen)
 	{
-		polar_amd_detail::check(polar_hip_encode(polar_amd_detail::context(), 0, (int8_t *)codeword, (const int8_t *)message, frozen, M, W, polar_hip_where(codeword)), "PolarEncoder");
+		int where = polar_amd_detail::where_of(codeword, message, "PolarEncoder");
+		polar_amd_detail::check(polar_amd_detail::encode(polar_amd_detail::context(), 0, (VALUE *)codeword, (const VALUE *)message, frozen, M, W, where), "PolarEncoder");
 	}
 };
 
-template <int W, int M>
-class PolarSysEnc<GPU<int8_t, W>, M>
+template <typename VALUE, int W, int M>
+class PolarSysEnc<GPU<VALUE, W>, M>
 {
-	typedef GPU<int8_t, W> TYPE;
+	typedef GPU<VALUE, W> TYPE;
 public:
 	void operator()(TYPE *codeword, const TYPE *message, const uint8_t *frozen)
 	{
-		polar_amd_detail::check(polar_hip_encode(polar_amd_detail::context(), 1, (int8_t *)codeword, (const int8_t *)message, frozen, M, W, polar_hip_where(codeword)), "PolarSysEnc");
+		int where = polar_amd_detail::where_of(codeword, message, "PolarSysEnc");
+		polar_amd_detail::check(polar_amd_detail::encode(polar_amd_detail::context(), 1, (VALUE *)codeword, (const VALUE *)message, frozen, M, W, where), "PolarSysEnc");
 	}
 };
 
@@ -120,12 +151,13 @@ public:
 // programs stay resident (a few digests are remembered here, and polar_hip_load_program returns
 // the id of a program it already holds), so repeated calls (testbench.cc:171) and callers that
 // alternate between codes neither re-upload nor grow the handle.
-template <int W, int MAX_M>
-class PolarDecoder<GPU<int8_t, W>, MAX_M>
+template <typename VALUE, int W, int MAX_M>
+class PolarDecoder<GPU<VALUE, W>, MAX_M>
 {
-	typedef GPU<int8_t, W> TYPE;
+	typedef GPU<VALUE, W> TYPE;
 	enum { REMEMBERED = 8 };
 	uint64_t digests[REMEMBERED] = {};
+	int lengths[REMEMBERED] = {};
 	int ids[REMEMBERED] = {-1, -1, -1, -1, -1, -1, -1, -1};
 	int next = 0;
 	static int length_of(const uint8_t *program)
@@ -146,15 +178,17 @@ public:
 			dg = (dg ^ program[i]) * 0x100000001b3ull;
 		int program_id = -1;
 		for (int k = 0; k < REMEMBERED; ++k)
-			if (ids[k] >= 0 && digests[k] == dg)
+			if (ids[k] >= 0 && digests[k] == dg && lengths[k] == n)
 				program_id = ids[k];
 		if (program_id < 0) {
 			program_id = polar_hip_load_program(polar_amd_detail::context(), program, n);
 			polar_amd_detail::check(program_id, "PolarDecoder (program)");
 			digests[next] = dg;
+			lengths[next] = n;
 			ids[next] = program_id;
 			next = (next + 1) % REMEMBERED;
 		}
-		polar_amd_detail::check(polar_hip_decode(polar_amd_detail::context(), program_id, (int8_t *)message, (const int8_t *)codeword, W, polar_hip_where(codeword)), "PolarDecoder");
+		int where = polar_amd_detail::where_of(codeword, message, "PolarDecoder");
+		polar_amd_detail::check(polar_amd_detail::decode(polar_amd_detail::context(), program_id, (VALUE *)message, (const VALUE *)codeword, W, where), "PolarDecoder");
 	}
 };

@@ -146,6 +146,15 @@ int polar_hip_decode_async(polar_hip_handle *h, int program_id, int8_t *message,
  * int8 decoder (one frame per lane, all state in HBM), not for throughput. */
 int polar_hip_decode_f32(polar_hip_handle *h, int program_id, float *message, const float *codeword, size_t frames, int where);
 
+/* PolarEncoder / PolarSysEnc with float lanes (polar_encoder.hh:9-59 is generic in TYPE; the bench
+ * selects it with `typedef float code_type`, testbench.cc:49-53). message: K x frames, codeword:
+ * N x frames floats. Symbols must be +1, -1 or 0 (what the bench feeds and every decoder returns);
+ * they are exact in either type, so the transform runs on the int8 kernels between two conversions
+ * and the result equals the reference's products of floats (no -0 arises: PolarHelper<float>::one()
+ * is +1 and (+-1) * (+-1) has no zero operand; a 0 symbol gives +0 or -0 in the reference depending on
+ * the sign of its partner and +0 here). Anything else is rejected with POLAR_E_ARG. */
+int polar_hip_encode_f32(polar_hip_handle *h, int systematic, float *codeword, const float *message, const uint8_t *frozen, int level, size_t frames, int where);
+
 /* No counterpart in the reference: polar_hip_decode_async for callers that cannot allocate --
  * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc. The
  * wavefront scratch arenas come from a file-scope device array of POLAR_STATIC_SCRATCH_BYTES
@@ -210,6 +219,12 @@ int polar_hip_random_message(polar_hip_handle *h, int8_t *message, size_t rows, 
  * codeword and llr: rows x frames; they may not alias. */
 int polar_hip_channel(polar_hip_handle *h, int8_t *llr, const int8_t *codeword, size_t rows, size_t frames, double snr_db, uint64_t seed, uint64_t first_frame, int where);
 
+/* The channel of the float bench (code_type = float, testbench.cc:49-53, 151-165): llr = (float)(2 / sigma^2 *
+ * (codeword + sigma * n)), unquantised (PolarHelper<float>::quant is the identity, polar_helper.hh:28-32), from
+ * the same noise draws as polar_hip_channel. codeword: +1 / -1 / 0 as floats (else POLAR_E_ARG); llr
+ * may be the same buffer, as in the reference (testbench.cc:164-165). */
+int polar_hip_channel_f32(polar_hip_handle *h, float *llr, const float *codeword, size_t rows, size_t frames, double snr_db, uint64_t seed, uint64_t first_frame, int where);
+
 /* One SNR point of the bench loop, testbench.cc:125-193, for frames [first_frame, first_frame +
  * frames) entirely on the device: random message -> PolarEncoder / PolarSysEnc -> channel ->
  * PolarDecoder -> (systematic: re-encode + gather) -> counters. Adds to counters[0..3] as
@@ -217,6 +232,12 @@ int polar_hip_channel(polar_hip_handle *h, int8_t *llr, const int8_t *codeword, 
  * testbench.cc:197). `where` places `counters` (int64[6]) on the host or the device (ready for
  * the RCCL all-reduce across frame shards); the frame buffers are internal and chunked. */
 int polar_hip_simulate(polar_hip_handle *h, int program_id, const uint8_t *frozen, int level, int systematic, double snr_db,
+	uint64_t seed, uint64_t first_frame, size_t frames, int64_t *counters, int where);
+
+/* The same loop with code_type = float (testbench.cc:49-53): same message and noise draws (so both
+ * decoders meet the very same frames), LLR = (float)(2 / sigma^2 * y) unquantised (PolarHelper<float>::quant
+ * is the identity, polar_helper.hh:28-32), polar_hip_decode_f32, float comparisons in the counters. */
+int polar_hip_simulate_f32(polar_hip_handle *h, int program_id, const uint8_t *frozen, int level, int systematic, double snr_db,
 	uint64_t seed, uint64_t first_frame, size_t frames, int64_t *counters, int where);
 
 /* Blocks until all work enqueued through this handle has finished. */

@@ -531,6 +531,25 @@ void oracle_channel(int8_t *llr, const int8_t *codeword, size_t rows, size_t fra
 		}
 }
 
+/* the float bench's channel (code_type = float, testbench.cc:49-53): the same draws, quant = identity
+ * (polar_helper.hh:28-32), the double product narrowed to float on assignment (testbench.cc:164-165) */
+void oracle_channel_f32(float *llr, const int8_t *codeword, size_t rows, size_t frames, double snr_db, uint64_t seed, uint64_t first_frame)
+{
+	double sigma = sqrt(1.0 / (2.0 * pow(10.0, snr_db / 10.0)));
+	double fact = 2.0 / (sigma * sigma);
+	for (size_t i = 0; i < rows; ++i)
+		for (size_t f = 0; f < frames; ++f) {
+			uint64_t g = first_frame + f;
+			uint32_t w[4];
+			oracle_draw(w, seed, 0, (uint32_t)i, g >> 2);
+			int pair = (int)(g & 2);
+			double u1 = ((double)w[pair] + 0.5) / 4294967296.0, u2 = ((double)w[pair + 1] + 0.5) / 4294967296.0;
+			double r = sqrt(-2.0 * log(u1)), t = 6.283185307179586476925286766559 * u2;
+			double n = (g & 1) ? r * sin(t) : r * cos(t);
+			llr[i * frames + f] = (float)(fact * ((double)codeword[i * frames + f] + sigma * n));
+		}
+}
+
 /* ---- float decoder: PolarDecoder<SIMD<float,W>,M> with PolarHelper<SIMD<VALUE,WIDTH>>
  *      (polar_helper.hh:62-111), the instantiation the reference bench selects with
  *      `typedef float code_type` (testbench.cc:49-53). TEST INFRASTRUCTURE ONLY.

@@ -212,16 +212,25 @@ class Session:
         (pl, wl), (pc, wc) = _ptr(llr), _ptr(codeword)
         if tuple(llr.shape) != tuple(codeword.shape):
             raise PolarError(-1, "channel: llr and codeword must have the same shape")
+        if _is_f32(llr) or _is_f32(codeword):  # the float bench: unquantised LLRs (testbench.cc:49-53)
+            if not (_is_f32(llr) and _is_f32(codeword)):
+                raise ValueError("the float channel needs float32 llr and codeword buffers")
+            _check(lib.polar_hip_channel_f32(self._h, pl, pc, int(codeword.shape[0]), _frames(codeword), float(snr_db), int(seed), int(first_frame), _where(wl, wc)), "polar_hip_channel_f32")
+            return
         _check(lib.polar_hip_channel(self._h, pl, pc, int(codeword.shape[0]), _frames(codeword), float(snr_db), int(seed), int(first_frame), _where(wl, wc)), "polar_hip_channel")
 
-    def simulate(self, counters, program, frozen, level, systematic, snr_db, seed, first_frame, frames):
+    def simulate(self, counters, program, frozen, level, systematic, snr_db, seed, first_frame, frames, code_type="int8"):
         """One SNR point of testbench.cc:125-193 on the device; counters: int64[6] (host numpy or
-        device tensor), added to."""
+        device tensor), added to. code_type "float": the bench's `typedef float code_type`
+        (testbench.cc:49-53), same frames, unquantised LLRs, float decoder."""
         pid, _rows = self.load_program(program)
         fz = np.ascontiguousarray(frozen, dtype=np.uint8)
         self._order(counters)
         pc, where = _ptr(counters)
-        _check(lib.polar_hip_simulate(self._h, pid, fz.ctypes.data, int(level), int(bool(systematic)), float(snr_db), int(seed), int(first_frame), int(frames), pc, where), "polar_hip_simulate")
+        if code_type not in ("int8", "float"):
+            raise ValueError("code_type must be 'int8' or 'float'")
+        fn = lib.polar_hip_simulate if code_type == "int8" else lib.polar_hip_simulate_f32
+        _check(fn(self._h, pid, fz.ctypes.data, int(level), int(bool(systematic)), float(snr_db), int(seed), int(first_frame), int(frames), pc, where), "polar_hip_simulate")
 
     def unpack_symbols(self, symbols, sign_plane, erasure_plane=None):
         """symbols[rows][frames] (+1 / -1 / 0) from the bit planes of extract_systematic_packed."""
@@ -309,6 +318,11 @@ class _Encoder:
         self.session._order(codeword)
         cp, cw = _ptr(codeword)
         mp, mw = _ptr(message)
+        if _is_f32(codeword) or (message is not None and _is_f32(message)):  # TYPE = float lanes (testbench.cc:49-53)
+            if not (_is_f32(codeword) and (message is None or _is_f32(message))):
+                raise ValueError("float encoding needs float32 codeword and message buffers")
+            _check(lib.polar_hip_encode_f32(self.session._h, self.systematic, cp, mp, frozen.ctypes.data, self.M, _frames(codeword), _where(cw, mw)), type(self).__name__ + "(float)")
+            return
         _check(lib.polar_hip_encode(self.session._h, self.systematic, cp, mp, frozen.ctypes.data, self.M, _frames(codeword), _where(cw, mw)), type(self).__name__)
 
 

@@ -30,8 +30,11 @@ struct DecodeArgs {
 // The occupancy hint stays at 4 waves per SIMD for every variant. The 20 KiB-of-LDS variants
 // cannot reach it (8 workgroups per CU) and the compiler then uses ~200 VGPRs anyway, but asking
 // for 2 instead made it schedule the chain loops worse: 15 % slower, measured A/B on one box.
+#ifndef POLAR_WAVES_PER_EU
+#define POLAR_WAVES_PER_EU 4
+#endif
 template <int Q, int RL>
-__global__ void __launch_bounds__(64, 4) sc_decode_kernel(DecodeArgs a)
+__global__ void __launch_bounds__(64, POLAR_WAVES_PER_EU) sc_decode_kernel(DecodeArgs a)
 {
 	typedef Group<Q, RL> G;
 	__shared__ __attribute__((aligned(16))) u32 lds[G::LDS_DWORDS];

@@ -584,6 +584,82 @@ struct Group {
 	}
 	// U independent final indices t, t + step, ... per lane: all 2^D * U loads are issued before
 	// the first use, which is what keeps enough bytes in flight for the HBM-resident levels
+	template <int D, class E, int U, class A>
+	PDEV void chain_load(E (&x)[U][1 << D], const A &a, int t, int nd, int step)
+	{
+		if (src_hot(a)) { // one branch for the whole block of loads, not one per load
+			POLAR_KEEP_APART();
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+#pragma unroll
+				for (int j = 0; j < (1 << D); ++j)
+					x[u][j] = ldH(a, t + u * step + j * nd, E());
+			POLAR_KEEP_APART();
+		} else {
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+#pragma unroll
+				for (int j = 0; j < (1 << D); ++j)
+					x[u][j] = ldC(a, t + u * step + j * nd, E());
+		}
+	}
+	template <int D, bool HZ, class E, int U, class H>
+	PDEV void chain_fold(E (&x)[U][1 << D], int lvl, u32 pad, const H *hs, const H *hz, u32 eb, int t, int nd, int step)
+	{
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int tu = t + u * step;
+#pragma unroll
+			for (int k = 1; k <= D; ++k) {
+				const int half = 1 << (D - k);
+				int kind = chain_kind(pad, k);
+				if (kind == 0) {
+#pragma unroll
+					for (int j = 0; j < half; ++j)
+						x[u][j] = prod4(x[u][j], x[u][j + half]);
+				} else if (kind == 2) {
+#pragma unroll
+					for (int j = 0; j < half; ++j)
+						x[u][j] = qadd4(x[u][j], x[u][j + half]);
+				} else {
+#pragma unroll
+					for (int j = 0; j < half; ++j)
+						x[u][j] = madd_at<HZ>(hs, hz, eb, tu + j * nd, x[u][j], x[u][j + half]);
+				}
+				if (!chain_skip(pad, k)) {
+#pragma unroll
+					for (int j = 0; j < half; ++j)
+						stE(lvl - k, tu + j * nd, x[u][j]);
+				}
+			}
+		}
+	}
+	// The same pass with the loads of the next block of final indices issued before the current
+	// block is folded and stored (two register buffers): a wavefront's memory stream does not
+	// pause for its arithmetic. S = final indices per block, nd a multiple of S (both powers of
+	// two times Q), so the trip count is wave-uniform.
+	template <int D, bool HZ, class E, int U, class A, class H>
+	PDEV void chain_pipelined(const A &a, int lvl, u32 pad, const H *hs, const H *hz, u32 eb, int t, int nd, int step, int S)
+	{
+		E xa[U][1 << D], xb[U][1 << D];
+		chain_load<D, E, U>(xa, a, t, nd, step);
+		for (;;) {
+			const bool more1 = t + S < nd;
+			if (more1)
+				chain_load<D, E, U>(xb, a, t + S, nd, step);
+			chain_fold<D, HZ, E, U>(xa, lvl, pad, hs, hz, eb, t, nd, step);
+			if (!more1)
+				break;
+			t += S;
+			const bool more2 = t + S < nd;
+			if (more2)
+				chain_load<D, E, U>(xa, a, t + S, nd, step);
+			chain_fold<D, HZ, E, U>(xb, lvl, pad, hs, hz, eb, t, nd, step);
+			if (!more2)
+				break;
+			t += S;
+		}
+	}
 	template <int D, bool HZ, class E, int U, class A, class H>
 	PDEV void chain_lane(const A &a, int lvl, u32 pad, const H *hs, const H *hz, u32 eb, int t, int nd, int step)
 	{
@@ -640,6 +716,16 @@ struct Group {
 #define POLAR_INFLIGHT 16
 #endif
 		const int U = SrcIsLds<A>::value ? 1 : (POLAR_INFLIGHT >> D) > 0 ? (POLAR_INFLIGHT >> D) : 1;
+#ifdef POLAR_PIPELINE
+		// from POLAR_PIPELINE blocks per lane on, scratch / input sources only
+		if (!SrcIsLds<A>::value && Q % 4 == 0 && nd >= 256 * U * POLAR_PIPELINE) {
+			PFOR_LANES(lane) {
+				chain_pipelined<D, HZ, u32x4, U>(a, lvl, pad, hs, hz, eb, lane * 4, nd, 256, 256 * U);
+			}
+			wave_sync();
+			return;
+		}
+#endif
 		if (U > 1 && nd >= 256 * U) {
 			PFOR_LANES(lane) {
 				for (int t = lane * 4; t < nd; t += 256 * U)

@@ -138,6 +138,12 @@ class Oracle:
         self.L.oracle_channel(_ptr(out), _ptr(codeword), ctypes.c_size_t(codeword.shape[0]), ctypes.c_size_t(codeword.shape[1]), ctypes.c_double(snr_db), ctypes.c_uint64(seed), ctypes.c_uint64(first_frame))
         return out
 
+    def channel_f32(self, codeword, snr_db, seed, first_frame=0):
+        codeword = _c(codeword, np.int8)
+        out = np.zeros(codeword.shape, np.float32)
+        self.L.oracle_channel_f32(_ptr(out), _ptr(codeword), ctypes.c_size_t(codeword.shape[0]), ctypes.c_size_t(codeword.shape[1]), ctypes.c_double(snr_db), ctypes.c_uint64(seed), ctypes.c_uint64(first_frame))
+        return out
+
     def quant(self, x):
         return np.array([self.L.oracle_quant(float(v)) for v in np.ravel(x)], np.int8).reshape(np.shape(x))
 

@@ -591,6 +591,57 @@ def test_float_decoder_vs_oracle(session, oracle):
     assert (f == msg).all() and (_decode(session, llr, prog, 1 << (M - 1)) == msg).all()
 
 
+def test_float_bench_path(session, oracle):
+    """SURVEY 8 f3 through the functor interface (`typedef float code_type`, testbench.cc:49-53):
+    float encoders, float channel and polar_hip_simulate_f32 against the oracle's pieces. Symbols
+    are exact in float; the channel passes through double log / sqrt / sin / cos on both sides and
+    is then narrowed to float, so its stated tolerance is: at most 1 LLR in 10^4 differing, and by
+    no more than 2 float ulps. The counters are exact on the device's own LLRs."""
+    import polar_amd
+
+    for M, frames, systematic, snr in ((8, 200, 0, 1.0), (10, 333, 1, -1.0), (11, 70, 1, -3.0)):
+        N = 1 << M
+        K = N // 2
+        fro = _code(oracle, M)
+        prog = oracle.compile(fro, M)
+        seed, first = 31 + M, 12
+        msg = oracle.random_message(K, frames, seed, first)
+        msgf = msg.astype(np.float32)
+        for sysm, enc in ((0, polar_amd.PolarEncoder(M, session)), (1, polar_amd.PolarSysEnc(M, session))):
+            exp = oracle.encode(msg, fro, M, sysm).astype(np.float32)
+            cwf = np.full((N, frames), 9.0, np.float32)
+            enc(cwf, msgf, fro)
+            assert (cwf == exp).all(), (M, sysm)
+            d = torch.zeros((N, frames), dtype=torch.float32, device="cuda")
+            enc(d, torch.from_numpy(msgf).cuda(), fro)
+            assert (d.cpu().numpy() == exp).all(), (M, sysm, "device")
+            with pytest.raises(polar_amd.PolarError):
+                enc(cwf, msgf * 0.5, fro)  # not symbols: the int8 kernels cannot carry them
+        cw = oracle.encode(msg, fro, M, systematic)
+        llr = np.zeros((N, frames), np.float32)
+        session.channel(llr, cw.astype(np.float32), snr, seed, first)
+        exp = oracle.channel_f32(cw, snr, seed, first)
+        off = llr != exp
+        assert off.mean() <= 1e-4 and (np.abs(llr - exp)[off] <= 2 * np.spacing(np.abs(exp[off]))).all(), (M, int(off.sum()))
+        got = np.zeros(6, np.int64)
+        session.simulate(got, prog, fro, M, systematic, snr, seed, first, frames, code_type="float")
+        dec = oracle.decode_f32(llr, prog).astype(np.int8)
+        if systematic:
+            dec = oracle.systematic_extract(dec, fro, M)
+        want = [int((llr * cw < 0).sum()), int((llr == 0).sum()), int((dec.astype(int) * msg <= 0).sum()), int((dec == 0).sum())]
+        assert got[:4].tolist() == want, (M, got, want)
+        assert got[4] == frames and got[5] == frames * K
+        d = torch.zeros(6, dtype=torch.int64, device="cuda")
+        session.simulate(d, prog, fro, M, systematic, snr, seed, first, 64, code_type="float")
+        session.simulate(d, prog, fro, M, systematic, snr, seed, first + 64, frames - 64, code_type="float")
+        assert d.cpu().numpy().tolist() == got.tolist()
+        # the two code types meet the same frames: well above the waterfall both decode everything
+        a, b = np.zeros(6, np.int64), np.zeros(6, np.int64)
+        session.simulate(a, prog, fro, M, systematic, 6.0, seed, first, frames)
+        session.simulate(b, prog, fro, M, systematic, 6.0, seed, first, frames, code_type="float")
+        assert a[2] == 0 and b[2] == 0 and a[4:].tolist() == b[4:].tolist()
+
+
 def test_code_cache_and_sweep_harness(session, oracle):
     """the handle's (level, K, p) cache returns the reference's construction and one
     resident program per key; the sweep harness on top of polar_hip_simulate prints the reference's
@@ -664,3 +715,8 @@ def test_cpp_dropin_header():
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "dropin device ok" in r.stdout, r.stdout + r.stderr
+    # the bench's float build, TYPE = GPU<float, W> (tests/cpp/dropin_float_test.cc)
+    exe = os.path.join(ROOT, "tests", "cpp", "dropin_float_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "dropin float ok" in r.stdout, r.stdout + r.stderr

@@ -200,8 +200,9 @@ def test_cpp_dropin_header_compiles():
     import tempfile
 
     with tempfile.TemporaryDirectory() as d:
-        subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"),
-                        os.path.join(ROOT, "tests", "cpp", "dropin_test.cc"), "-L" + os.path.join(ROOT, "polar_amd"), "-lpolar_hip"], check=True)
+        for src in ("dropin_test.cc", "dropin_float_test.cc"):
+            subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"),
+                            os.path.join(ROOT, "tests", "cpp", src), "-L" + os.path.join(ROOT, "polar_amd"), "-lpolar_hip"], check=True)
 
 
 def test_product_construction_at_other_rates_and_design_points():
