@@ -27,14 +27,11 @@ struct DecodeArgs {
 // Persistent wavefronts: block b walks the groups b, b + gridDim, ... Blocks are dealt to
 // the 8 XCDs round-robin, so within one sweep the blocks that share an XCD (equal b % 8) take
 // neighbouring groups: those groups share the 128-byte lines of every input row.
-// The occupancy hint stays at 4 waves per SIMD for every variant. The 20 KiB-of-LDS variants
-// cannot reach it (8 workgroups per CU) and the compiler then uses ~200 VGPRs anyway, but asking
-// for 2 instead made it schedule the chain loops worse: 15 % slower, measured A/B on one box.
-#ifndef POLAR_WAVES_PER_EU
-#define POLAR_WAVES_PER_EU 4
-#endif
+// Occupancy hint: 4 waves per SIMD, which the variants with more than 10 KiB of LDS cannot reach; the
+// compiler then budgets their registers by what the LDS allows. The pipelined variants (Group::PIPELINE)
+// state their two waves per SIMD outright: a hard 256-register budget, else the compiler takes 260.
 template <int Q, int RL>
-__global__ void __launch_bounds__(64, POLAR_WAVES_PER_EU) sc_decode_kernel(DecodeArgs a)
+__global__ void __launch_bounds__(64, (Group<Q, RL>::PIPELINE ? 2 : 4)) sc_decode_kernel(DecodeArgs a)
 {
 	typedef Group<Q, RL> G;
 	__shared__ __attribute__((aligned(16))) u32 lds[G::LDS_DWORDS];

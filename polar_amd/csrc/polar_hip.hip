@@ -1269,6 +1269,9 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	a.cw = cw;
 	a.msg = msg;
 	a.stride = padded;
+	if (const char *e = getenv("POLAR_HIP_ROW_STRIDE")) // experiments: the caller's rows are this many bytes apart (a multiple of 16)
+		if (direct && (size_t)atol(e) >= padded && atol(e) % 16 == 0)
+			a.stride = (size_t)atol(e);
 	a.groups = (u32)groups;
 	a.top = lp.host.top;
 	a.hot_top = v->rl;

@@ -130,11 +130,17 @@ PDEV u32 prod_half(u32 x, u32 y)
 }
 PDEV u32 prod4(u32 a, u32 b)
 {
+#ifdef POLAR_FAKE_ARITH // diagnostic: the kernel's memory traffic without its arithmetic (wrong results, no erasures)
+	return a | (b & 0x01010101u);
+#endif
 	return merge(prod_half(split_hi(a), split_hi(b)), prod_half(split_lo(a), split_lo(b)));
 }
 // qadd (polar_helper.hh:141-144)
 PDEV u32 qadd4(u32 a, u32 b)
 {
+#ifdef POLAR_FAKE_ARITH
+	return a | (b & 0x01010101u) | 0x01010101u;
+#endif
 	return merge(pk_add_sat(split_hi(a), split_hi(b)), pk_add_sat(split_lo(a), split_lo(b)));
 }
 // 16-bit lane masks from sign bits: m_hi from bits 15/31, m_lo from bits 7/23
@@ -144,6 +150,9 @@ PDEV u32 mask_lo(u32 s) { u32 t = s << 8; return perm(t, t, 0x09090808u); }
 // zero bits of h on the byte sign bits (other bits are ignored).
 PDEV u32 madd4(u32 hs, u32 hz, u32 a, u32 b)
 {
+#ifdef POLAR_FAKE_ARITH
+	return b | (a & 0x01010101u) | ((hs & hz) & 0x02020202u) | 0x01010101u;
+#endif
 	const u32 K = 0x81008100u; // -127 * 256 per half
 	u32 ah = pk_max(split_hi(a), K), al = pk_max(split_lo(a), K);
 	u32 bh = split_hi(b), bl = split_lo(b);
@@ -156,6 +165,9 @@ PDEV u32 madd4(u32 hs, u32 hz, u32 a, u32 b)
 // madd with a partial sum that is known to be +1 / -1 (no erasure): vqadd(vsign(vmax(a,-127), h), b)
 PDEV u32 madd4_nz(u32 hs, u32 a, u32 b)
 {
+#ifdef POLAR_FAKE_ARITH
+	return b | (a & 0x01010101u) | (hs & 0x02020202u) | 0x01010101u;
+#endif
 	const u32 K = 0x81008100u;
 	u32 ah = pk_max(split_hi(a), K), al = pk_max(split_lo(a), K);
 	u32 bh = split_hi(b), bl = split_lo(b);
@@ -434,6 +446,18 @@ struct Group {
 	// deepest fused descent: 16 x 16-byte loads per lane need more than the 128 VGPRs that the
 	// variants with 16 wavefronts per CU have (99 spilled registers, 12 % slower when tried)
 	static const int CHAIN_DEPTH = LDS_DWORDS * 4 > 10240 ? 4 : 3;
+	// Wavefronts per SIMD the kernel is built for (its LDS share allows no more): 4 with ~10 KiB, 2 with
+	// ~20 KiB, 1 beyond. Stated outright (__launch_bounds__) the 20 KiB class gets a hard 256-register
+	// budget, which the pipelined chain passes (two load buffers of 64 registers) need to stay at two.
+	static const int WAVES_PER_SIMD = LDS_DWORDS * 4 <= 10240 ? 4 : LDS_DWORDS * 4 <= 20480 ? 2 : 1;
+#ifndef POLAR_PIPELINE
+#define POLAR_PIPELINE 1
+#endif
+	// chain passes over scratch / input rows issue the next block's loads before they fold and store the
+	// current one (chain_pipelined): +1.5 % at 2^20 frames of N = 2^16 (profiles/r3_experiment_pipelined_chains.txt).
+	// Single-wavefront groups of 64 frames and more in the 20 KiB class only: the team kernels have no registers
+	// to spare, and narrower groups have few passes that long.
+	static const bool PIPELINE = POLAR_PIPELINE && !TEAM && WAVES_PER_SIMD == 2 && Q >= 16;
 	lds_u32 *sl;        // LDS soft arena, LDS_SOFT dwords (level l at Q << l)
 	lds_u32 *hls, *hlz; // LDS partial-sum planes (sign, zero), LDS_PLANE dwords each, index by position mod W
 	u32 *sg;            // scratch soft arena, Q << top dwords
@@ -716,16 +740,14 @@ struct Group {
 #define POLAR_INFLIGHT 16
 #endif
 		const int U = SrcIsLds<A>::value ? 1 : (POLAR_INFLIGHT >> D) > 0 ? (POLAR_INFLIGHT >> D) : 1;
-#ifdef POLAR_PIPELINE
-		// from POLAR_PIPELINE blocks per lane on, scratch / input sources only
-		if (!SrcIsLds<A>::value && Q % 4 == 0 && nd >= 256 * U * POLAR_PIPELINE) {
+		// from two blocks per lane on, scratch / input sources only
+		if (PIPELINE && !SrcIsLds<A>::value && Q % 4 == 0 && nd >= 256 * U * 2) {
 			PFOR_LANES(lane) {
 				chain_pipelined<D, HZ, u32x4, U>(a, lvl, pad, hs, hz, eb, lane * 4, nd, 256, 256 * U);
 			}
 			wave_sync();
 			return;
 		}
-#endif
 		if (U > 1 && nd >= 256 * U) {
 			PFOR_LANES(lane) {
 				for (int t = lane * 4; t < nd; t += 256 * U)
