@@ -234,6 +234,15 @@ int polar_hip_channel_f32(polar_hip_handle *h, float *llr, const float *codeword
 int polar_hip_simulate(polar_hip_handle *h, int program_id, const uint8_t *frozen, int level, int systematic, double snr_db,
 	uint64_t seed, uint64_t first_frame, size_t frames, int64_t *counters, int where);
 
+/* The one exchange of the sharded bench (SURVEY 8 e): frames are independent, every GPU simulates its own
+ * shard [first_frame, first_frame + frames) into device counters (polar_hip_simulate / polar_hip_count with
+ * POLAR_DEVICE), and the int64 counters of testbench.cc:119-125, 185-192 are summed over the ranks of the
+ * caller's RCCL communicator (`nccl_comm` = its ncclComm_t), in place, on the handle's stream; returns
+ * when the sums are there. One process per GPU, every rank calls it with the same `count`. The library does
+ * not link RCCL: it uses the ncclAllReduce of the RCCL already in the process (the one the communicator came
+ * from), else loads librccl.so. No counterpart in the reference (one process, one counter set). */
+int polar_hip_allreduce_counters(polar_hip_handle *h, int64_t *counters, size_t count, void *nccl_comm);
+
 /* The same loop with code_type = float (testbench.cc:49-53): same message and noise draws (so both
  * decoders meet the very same frames), LLR = (float)(2 / sigma^2 * y) unquantised (PolarHelper<float>::quant
  * is the identity, polar_helper.hh:28-32), polar_hip_decode_f32, float comparisons in the counters. */

@@ -45,6 +45,7 @@ SYMBOLS = {
     "polar_hip_random_message": ([_vp, _vp, _sz, _sz, ctypes.c_uint64, ctypes.c_uint64, _i], _i),
     "polar_hip_channel": ([_vp, _vp, _vp, _sz, _sz, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, _i], _i),
     "polar_hip_simulate": ([_vp, _i, _vp, _i, _i, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, _sz, _vp, _i], _i),
+    "polar_hip_allreduce_counters": ([_vp, _vp, _sz, _vp], _i),
     "polar_hip_synchronize": ([_vp], _i),
     "polar_hip_last_decode_ms": ([_vp], ctypes.c_float),
 }

@@ -720,3 +720,19 @@ def test_cpp_dropin_header():
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "dropin float ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_cpp_caller_shards_with_rccl():
+    """SURVEY 8 e for a C / C++ caller: polar_hip_simulate into device counters per shard, then
+    polar_hip_allreduce_counters over the caller's RCCL communicator (tests/cpp/shard_counters_test.cc,
+    built by __graft_entry__.build()); a world of one rank on this one-GPU box: two shards add up to
+    the whole batch, the all-reduce leaves the sums in place, misuse is refused."""
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = os.path.join(ROOT, "tests", "cpp", "shard_counters_test")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "shard counters ok" in r.stdout, r.stdout + r.stderr
