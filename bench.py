@@ -325,7 +325,7 @@ def library_sha16():
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("sc_core.hpp", "decode_kernel.hpp", "variants.hip", "program.hpp", "polar_hip.hip"):
+    for f in ("sc_core.hpp", "decode_kernel.hpp", "variants.hip", "program.hpp", "decode_launch.hpp", "handle.hpp"):
         h.update(open(os.path.join(ROOT, "polar_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -155,7 +155,10 @@ class Session:
     def _order(self, *arrays):
         """Device tensors are produced on torch's current stream: make it the handle's stream so
         the library's work queues behind the producers with no host synchronisation
-        (include/polar_hip.h, stream ordering)."""
+        (include/polar_hip.h, stream ordering). Calls without a device tensor go back to the handle's
+        private stream, so host-buffer work never lands on a stream the caller has meanwhile
+        destroyed or on torch's blocking null stream. The stream in use must outlive the call;
+        inputs produced on other streams than torch's current one are the caller's to synchronise."""
         for a in arrays:
             if a is not None and hasattr(a, "is_cuda") and a.is_cuda:
                 import torch
@@ -165,6 +168,9 @@ class Session:
                     _check(lib.polar_hip_set_stream(self._h, ctypes.c_void_p(st), 1), "polar_hip_set_stream")
                     self._stream = st
                 return
+        if self._stream is not None:
+            _check(lib.polar_hip_set_stream(self._h, None, 0), "polar_hip_set_stream")
+            self._stream = None
 
     def configure(self, frames_per_wave=0, lds_level=0, max_waves=0, team=1):
         _check(lib.polar_hip_configure_team(self._h, frames_per_wave, lds_level, team, max_waves), "polar_hip_configure")

@@ -1,0 +1,176 @@
+// decode_launch.hpp -- part of polar_hip.hip (one translation unit; included there, in this order): launch of the decode kernel: shape, arenas, hot levels, staging of ragged batches.
+#pragma once
+
+// Enqueues the decode of `frames` frames on `stream`. The kernel wants whole groups of 4Q frames
+// and dword-aligned rows; anything else is staged through padded device copies (zero-filled
+// tail frames decode to garbage that is never copied back).
+static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, hipStream_t stream, bool timed)
+{
+	LoadedProgram &lp = h->programs[program_id];
+	ScratchBudget budget{h};
+	const KernelVariant *v = pick_variant(h, lp.host.top, frames, budget);
+	if (!v)
+		return fail(POLAR_E_ARG, "no kernel variant for the configured (frames_per_wave, lds_level)");
+	const int shape = program_shape(v);
+	int rc;
+	if ((rc = upload_shape(lp, v))) // first use with this wavefront shape: fuse and upload
+		return rc;
+	// a workgroup takes `team` neighbouring groups at a time (1, or TEAM_WAVES in the team form)
+	const size_t team = (size_t)v->team, fpw = 4 * (size_t)v->q * team, n = (size_t)1 << lp.host.top, rows = lp.host.rows;
+	const size_t units = (frames + fpw - 1) / fpw, groups = units * team;
+	if (groups > 0x7FFFFFFFu)
+		return fail(POLAR_E_ARG, "too many frames for one call");
+	h->timed = false;
+	if (!groups)
+		return POLAR_OK;
+	const size_t padded = units * fpw;
+	const bool direct = padded == frames && (uintptr_t)codeword % 16 == 0 && (uintptr_t)message % 16 == 0;
+	const uint8_t *cw = (const uint8_t *)codeword;
+	uint8_t *msg = (uint8_t *)message;
+	if (!direct) {
+		if ((rc = h->pad_in.reserve(n * padded)) || (rc = h->pad_out.reserve((rows ? rows : 1) * padded)))
+			return rc;
+		HIP_TRY(hipMemsetAsync(h->pad_in.p, 0, n * padded, stream));
+		HIP_TRY(hipMemcpy2DAsync(h->pad_in.p, padded, codeword, frames, frames, n, hipMemcpyDeviceToDevice, stream));
+		cw = (const uint8_t *)h->pad_in.p;
+		msg = (uint8_t *)h->pad_out.p;
+	}
+	int per_cu = 0;
+	auto occ = h->occupancy.find((const void *)v->fn);
+	if (occ == h->occupancy.end()) {
+		HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, v->fn, 64 * v->team, 0));
+		h->occupancy[(const void *)v->fn] = per_cu;
+	} else {
+		per_cu = occ->second;
+	}
+	if (per_cu < 1)
+		return fail(POLAR_E_HIP, "decode kernel does not fit on a CU");
+	size_t blocks = (size_t)per_cu * h->cus;
+	if (h->cfg_max_waves && (size_t)h->cfg_max_waves / team < blocks)
+		blocks = (size_t)h->cfg_max_waves / team ? (size_t)h->cfg_max_waves / team : 1;
+	size_t block_dwords = 0, max_blocks = ~(size_t)0 >> 8;
+	if (lp.host.top > v->rl) { // LLR levels above the LDS levels and the partial-sum planes live in scratch
+		size_t soft = (size_t)v->q << lp.host.top;
+		block_dwords = soft + 2 * (soft / 8);
+		if (const char *e = getenv("POLAR_HIP_ARENA_PAD")) // experiments: dwords between the arenas (a multiple of 4)
+			block_dwords += (size_t)atoi(e) / 4 * 4;
+		if (!budget.fits(blocks * team * block_dwords * sizeof(u32))) { // fewer resident wavefronts, more sweeps
+			max_blocks = budget.limit() / (team * block_dwords * sizeof(u32));
+			if (max_blocks < 1)
+				return fail(POLAR_E_NOMEM, "not enough device memory for one wavefront's scratch arena");
+			if (blocks > max_blocks)
+				blocks = max_blocks;
+		}
+	}
+	// every wavefront walks the same number of groups: no idle tail behind a last partial sweep
+	size_t sweeps = (units + blocks - 1) / blocks;
+	blocks = (units + sweeps - 1) / sweeps;
+	if (blocks >= 8 && blocks % 8) // multiple of 8 for the XCD-aware group order
+		blocks = blocks + 8 - blocks % 8 <= max_blocks ? blocks + 8 - blocks % 8 : blocks - blocks % 8;
+	if (getenv("POLAR_HIP_DEBUG"))
+		fprintf(stderr, "polar_hip: decode Q=%d RL=%d team=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d hot levels <= %d\n", v->q, v->rl, v->team, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct, hot_top_for(v, lp.host.top, blocks * team));
+	h->last_shape[0] = 4 * v->q;
+	h->last_shape[1] = v->rl;
+	h->last_shape[2] = v->team;
+	DecodeArgs a;
+	a.prog = lp.dev[shape];
+	a.cw = cw;
+	a.msg = msg;
+	a.stride = padded;
+	if (const char *e = getenv("POLAR_HIP_ROW_STRIDE")) // experiments: the caller's rows are this many bytes apart (a multiple of 16)
+		if (direct && (size_t)atol(e) >= padded && atol(e) % 16 == 0)
+			a.stride = (size_t)atol(e);
+	a.groups = (u32)groups;
+	a.top = lp.host.top;
+	a.hot_top = v->rl;
+	a.hot = nullptr;
+	a.hot_dwords = 0;
+	a.scratch = nullptr;
+	a.block_dwords = 0;
+	if (block_dwords) {
+		a.block_dwords = block_dwords;
+		if ((rc = h->scratch.reserve(blocks * team * block_dwords * sizeof(u32))))
+			return rc;
+		a.scratch = (u32 *)h->scratch.p;
+		a.hot_top = hot_top_for(v, lp.host.top, blocks * team);
+		if (a.hot_top > v->rl) { // the wavefronts' hot levels side by side in one compact region
+			a.hot_dwords = ((size_t)v->q << (a.hot_top + 1)) - ((size_t)v->q << (v->rl + 1));
+			if ((rc = h->hot.reserve(blocks * team * a.hot_dwords * sizeof(u32))))
+				return rc;
+			a.hot = (u32 *)h->hot.p;
+		}
+	}
+	a.prof = nullptr;
+#ifdef POLAR_PROFILE
+	static unsigned long long *prof_dev = nullptr;
+	if (!prof_dev)
+		HIP_TRY(hipMalloc((void **)&prof_dev, 16 * 32 * 2 * 8));
+	HIP_TRY(hipMemsetAsync(prof_dev, 0, 16 * 32 * 2 * 8, stream));
+	a.prof = prof_dev;
+#endif
+	if (timed)
+		HIP_TRY(hipEventRecord(h->ev0, stream));
+	hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64 * (unsigned)team), 0, stream, a);
+	HIP_TRY(hipGetLastError());
+#ifdef POLAR_PROFILE
+	{
+		static unsigned long long host[16 * 32 * 2];
+		HIP_TRY(hipMemcpyAsync(host, prof_dev, sizeof(host), hipMemcpyDeviceToHost, stream));
+		HIP_TRY(hipStreamSynchronize(stream));
+		static const char *names[16] = {"left", "right", "comb", "rate0", "rate1", "rep", "spc", "r0right", "r0comb", "r1comb", "?", "chain1", "chain2", "chain3", "chain4", "?"};
+		unsigned long long total = 0;
+		for (int i = 0; i < 16 * 32; ++i)
+			total += host[2 * i];
+		fprintf(stderr, "polar_hip profile: wave-cycles per node kind and level (blocks=%zu, total %.3e cycles = %.1f Mcycles per wave)\n", blocks, (double)total, total / 1e6 / blocks);
+		for (int k = 0; k < 16; ++k)
+			for (int l = 0; l < 32; ++l)
+				if (host[2 * (k * 32 + l) + 1])
+					fprintf(stderr, "  %-8s L%-2d calls/wave %8.1f  cycles/call %9.0f  share %5.2f%%\n", names[k], l, (double)host[2 * (k * 32 + l) + 1] / blocks,
+						(double)host[2 * (k * 32 + l)] / host[2 * (k * 32 + l) + 1], 100.0 * host[2 * (k * 32 + l)] / total);
+	}
+#endif
+	if (timed) {
+		HIP_TRY(hipEventRecord(h->ev1, stream));
+		h->timed = true;
+	}
+	if (!direct && rows)
+		HIP_TRY(hipMemcpy2DAsync(message, frames, msg, padded, frames, rows, hipMemcpyDeviceToDevice, stream));
+	return POLAR_OK;
+}
+
+static int check_decode_args(polar_hip_handle *h, int program_id, const void *message, const void *codeword, size_t frames)
+{
+	if (!h)
+		return fail(POLAR_E_ARG, "polar_hip_decode: null handle");
+	if (program_id < 0 || (size_t)program_id >= h->programs.size())
+		return fail(POLAR_E_ARG, "polar_hip_decode: unknown program id");
+	if (frames && (!codeword || (!message && h->programs[program_id].host.rows)))
+		return fail(POLAR_E_ARG, "polar_hip_decode: null buffer");
+	return POLAR_OK;
+}
+
+// True when the runtime knows `p` as page-locked host memory (polar_hip_host_alloc, hipHostMalloc,
+// hipHostRegister): only then do asynchronous copies run beside the host thread.
+static bool host_pinned(const void *p)
+{
+	hipPointerAttribute_t attr;
+	if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+		(void)hipGetLastError(); // pageable memory is "invalid value" to this query
+		return false;
+	}
+	return attr.type == hipMemoryTypeHost;
+}
+
+// frames per chunk of the host-buffer pipeline: about 1 GiB of LLRs, never so few frames that the
+// decode of a chunk falls into the small-batch regime, whole groups of every kernel shape
+static size_t pipeline_chunk(size_t n)
+{
+	if (const char *e = getenv("POLAR_HIP_HOST_CHUNK")) { // frames; tests and experiments only
+		size_t c = (size_t)atoll(e);
+		return c < 512 ? 512 : c - c % 512;
+	}
+	size_t c = ((size_t)1 << 30) / n;
+	if (c < 16384)
+		c = 16384;
+	return c - c % 512;
+}
