@@ -77,6 +77,7 @@ def parse(argv=None):
     ap.add_argument("--plumbing-only", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo test of the rank plumbing
     ap.add_argument("--rank-timeout", type=float, default=1500.0, help="seconds the rank launcher waits for its children")
     ap.add_argument("--init-timeout", type=float, default=180.0, help="seconds a rank waits in the process-group rendezvous")
+    ap.add_argument("--force-dist", action="store_true", help="join the RCCL process group even as a world of one (rehearses the N > 1 path on a one-GPU box)")
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)  # test: this rank exits 3 at start
     return ap.parse_args(argv)
 
@@ -372,10 +373,14 @@ def main():
         raise SystemExit("bench.py: rank %d needs GPU %d but only %d GPU(s) are visible" % (rank, local, torch.cuda.device_count()))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:  # --force-dist on its own: a world of one needs the rendezvous variables too
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         import datetime
 
         dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=args.init_timeout))

@@ -415,7 +415,7 @@ extern "C" int polar_hip_code(polar_hip_handle *h, int level, int K, long double
 // can displace them, so they never travel to HBM (tools/ubench/hbm_ceiling.hip).
 static int hot_top_for(const KernelVariant *v, int top, size_t waves)
 {
-	if (v->team > 1) // the team kernels are built without hot levels (sc_core.hpp, Group::HOT)
+	if (v->team > 1 && !POLAR_TEAM_HOT) // the team kernels are built without hot levels (sc_core.hpp, Group::HOT)
 		return v->rl;
 	static const char *e = getenv("POLAR_HIP_HOT_LEVELS"); // experiments: number of hot levels
 	if (e)

@@ -54,6 +54,9 @@ enum : u32 {
 	OP_SUBTREE = 17,
 	OP_END = 255
 };
+#ifndef POLAR_TEAM_HOT
+#define POLAR_TEAM_HOT 0
+#endif
 #ifndef POLAR_HOT_ENABLE
 #define POLAR_HOT_ENABLE 1
 #endif
@@ -481,7 +484,7 @@ struct Group {
 	// fraction of the Infinity Cache's sets and evict one another (tools/ubench/sc_skeleton.hip:
 	// 5.5 TB/s spread, 6.6 TB/s compact for the same accesses).
 	// Not in the team kernels: they sit at the 256-register limit and the second code path spills.
-	static const bool HOT = !TEAM && POLAR_HOT_ENABLE;
+	static const bool HOT = (!TEAM || POLAR_TEAM_HOT) && POLAR_HOT_ENABLE;
 	PDEV bool is_hot(int lvl) const { return HOT && lvl <= hot_top; }
 	PDEV u32 *gregion(int lvl) const { return (is_hot(lvl) ? sh : sg) + (Q << lvl); }
 	PDEV GVec gvec(int lvl) const { return GVec{(glb_u32 *)gregion(lvl), is_hot(lvl)}; }

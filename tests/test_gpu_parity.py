@@ -736,3 +736,22 @@ def test_cpp_caller_shards_with_rccl():
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and "shard counters ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_joins_the_rccl_group_as_a_world_of_one():
+    """SURVEY 8 e: the N > 1 path of bench.py (init_process_group("nccl"), barriers, counter all-reduce,
+    max-over-ranks time) run on hardware with the only world size a one-GPU box offers. A small batch,
+    no CPU baseline: the line must parse and carry the counters."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--config", "A", "--frames", "32768", "--steps", "2", "--warmup", "1", "--cpu-seconds", "0"],
+                       capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
