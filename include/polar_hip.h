@@ -86,7 +86,10 @@ void polar_hip_destroy(polar_hip_handle *h);
 /* Tuning: frames per wavefront (4 ... 256) and highest LLR level staged in LDS -- one of the
  * compiled kernel variants, e.g. (128, 6), (64, 7), (256, 5), (16, 9); POLAR_E_ARG otherwise --
  * and the number of resident wavefronts (0 = fill the device). frames_per_wave = 0 restores the
- * default: chosen per call from the batch size, the code size and the free device memory. */
+ * default: chosen per call from the batch size, the code size and the free device memory -- for the
+ * whole device, or for max_waves resident wavefronts when that is set: handles that decode side by
+ * side on streams of their own (polar_hip_decode_async; mixed batches of several codes) each take a
+ * share of the device this way. */
 int polar_hip_configure(polar_hip_handle *h, int frames_per_wave, int lds_level, int max_waves);
 /* The same with the team size: wavefronts per workgroup that decode neighbouring groups side by
  * side and pace their passes over the input rows (1 = one wavefront per workgroup, what

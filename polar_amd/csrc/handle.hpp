@@ -443,7 +443,11 @@ static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, siz
 	// every resident wavefront has one -- two for 128 frames, whose one-sweep batches the 64-frame
 	// teams decode faster; groups of 32 frames already pay off when three eighths of the wavefronts
 	// have one, narrower ones when half of them do. Groups of 32 and 64 frames go in teams of four (whole 128-byte input lines).
-	const size_t resident = (size_t)8 * h->cus;
+	// a handle limited to a share of the device (polar_hip_configure: max_waves; several handles decoding
+	// side by side on their own streams) picks its shape for that share
+	size_t resident = (size_t)8 * h->cus;
+	if (h->cfg_max_waves && (size_t)h->cfg_max_waves < resident)
+		resident = (size_t)h->cfg_max_waves;
 	static const int family[][3] = {{32, 6, 1}, {16, 7, 4}, {8, 8, 4}, {4, 9, 1}, {2, 10, 1}, {1, 11, 1}};
 	for (const auto &f : family) {
 		size_t groups = (frames + 4 * f[0] - 1) / (4 * f[0]);
