@@ -14,7 +14,7 @@ extern "C" int polar_hip_decode(polar_hip_handle *h, int program_id, int8_t *mes
 		return POLAR_OK;
 	const HostProgram &hp = h->programs[program_id].host;
 	if (where == POLAR_DEVICE) {
-		if ((rc = launch_decode(h, program_id, message, codeword, frames, h->stream, true)))
+		if ((rc = launch_decode(h, program_id, message, codeword, frames, h->stream, true, true))) // a resident batch: the arenas' placement is watched
 			return rc;
 		HIP_TRY(hipStreamSynchronize(h->stream));
 		return POLAR_OK;
@@ -180,6 +180,7 @@ static int launch_decode_f32(polar_hip_handle *h, int program_id, float *msg, co
 	a.groups = (u32)groups;
 	a.top = lp.host.top;
 	h->timed = false;
+	h->placement.pending = false; // the timing events now belong to this launch
 	HIP_TRY(hipEventRecord(h->ev0, h->stream));
 	hipLaunchKernelGGL(sc_decode_f32_kernel, dim3((unsigned)blocks), dim3(64), 0, h->stream, a);
 	HIP_TRY(hipGetLastError());

@@ -1,10 +1,75 @@
 // decode_launch.hpp -- part of polar_hip.hip (one translation unit; included there, in this order): launch of the decode kernel: shape, arenas, hot levels, staging of ragged batches.
 #pragma once
 
+// Where the driver puts the arenas decides up to 5 % of the kernel time: the same 20 GiB allocation, at the
+// same virtual address, gives 219 or 231 ms for 2^20 frames of N = 2^16 depending on the physical memory
+// behind it, reproducibly per placement (profiles/r3_placement.txt). Nothing in user space tells a good
+// placement from a bad one except the clock, so a handle that decodes the same resident batch again and
+// again (polar_hip_decode with device pointers: the bench loop) measures: the first call runs on the
+// placement at hand; it is then set aside and the next call runs on newly allocated arenas; the faster of
+// the two stays, the other is freed; PLACEMENT_CANDIDATES new placements are looked at this way, one call
+// each, the best one is kept. Results do not depend on it. Arenas of 1 GiB and more, and only while a
+// second copy fits the free device memory; POLAR_HIP_PLACEMENT=0 turns it off.
+enum { PLACEMENT_CANDIDATES = 3 };
+static void placement_step(polar_hip_handle *h, int program_id, size_t frames, const KernelVariant *v, size_t bytes)
+{
+	static const bool off = getenv("POLAR_HIP_PLACEMENT") && atoi(getenv("POLAR_HIP_PLACEMENT")) == 0;
+	polar_hip_handle::Placement &t = h->placement;
+	const bool same = t.program == program_id && t.frames == frames && t.fn == (const void *)v->fn && t.bytes == bytes;
+	if (off || bytes < ((size_t)1 << 30) || !same) { // nothing to watch, or another workload: start over with the placement at hand
+		if (h->scratch_spare.p) { // a comparison was under way: the arenas set aside were the better ones so far
+			if (hipStreamSynchronize(h->stream) == hipSuccess) {
+				h->scratch.release();
+				std::swap(h->scratch, h->scratch_spare);
+			}
+		}
+		t = polar_hip_handle::Placement();
+		if (!off && bytes >= ((size_t)1 << 30)) {
+			t.program = program_id;
+			t.frames = frames;
+			t.fn = (const void *)v->fn;
+			t.bytes = bytes;
+		}
+		return;
+	}
+	if (!t.pending || t.done)
+		return;
+	t.pending = false;
+	float ms = 0;
+	bool ok = hipEventSynchronize(h->ev1) == hipSuccess && hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess && ms > 0;
+	ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
+	const bool debug = getenv("POLAR_HIP_DEBUG") != nullptr;
+	if (ok && h->scratch_spare.p) { // the call ran on a candidate: keep the faster of it and the one set aside
+		if (ms < t.best_ms) {
+			t.best_ms = ms;
+			h->scratch_spare.release();
+		} else {
+			h->scratch.release();
+			std::swap(h->scratch, h->scratch_spare);
+		}
+	} else if (ok) {
+		t.best_ms = ms;
+	}
+	if (debug)
+		fprintf(stderr, "polar_hip: arena placement %d: %.2f ms, best %.2f ms\n", t.tries, ms, t.best_ms);
+	size_t free_b = 0, total_b = 0;
+	if (!ok || t.tries >= PLACEMENT_CANDIDATES || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + ((size_t)4 << 30)) {
+		t.done = true;
+		return;
+	}
+	++t.tries;
+	std::swap(h->scratch, h->scratch_spare); // set the best aside; the reserve that follows allocates the candidate
+	if (h->scratch.reserve(bytes) != POLAR_OK) { // no room after all: go on with what we have
+		(void)hipGetLastError();
+		std::swap(h->scratch, h->scratch_spare);
+		t.done = true;
+	}
+}
+
 // Enqueues the decode of `frames` frames on `stream`. The kernel wants whole groups of 4Q frames
 // and dword-aligned rows; anything else is staged through padded device copies (zero-filled
 // tail frames decode to garbage that is never copied back).
-static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, hipStream_t stream, bool timed)
+static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, hipStream_t stream, bool timed, bool tune_placement = false)
 {
 	LoadedProgram &lp = h->programs[program_id];
 	ScratchBudget budget{h};
@@ -68,6 +133,8 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	if (blocks >= 8 && blocks % 8) // multiple of 8 for the XCD-aware group order
 		blocks = blocks + 8 - blocks % 8 <= max_blocks ? blocks + 8 - blocks % 8 : blocks - blocks % 8;
 	if (getenv("POLAR_HIP_DEBUG"))
+		fprintf(stderr, "polar_hip: scratch %p (%zu MiB) hot %p (%zu MiB)\n", h->scratch.p, h->scratch.bytes >> 20, h->hot.p, h->hot.bytes >> 20);
+	if (getenv("POLAR_HIP_DEBUG"))
 		fprintf(stderr, "polar_hip: decode Q=%d RL=%d team=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d hot levels <= %d\n", v->q, v->rl, v->team, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct, hot_top_for(v, lp.host.top, blocks * team));
 	h->last_shape[0] = 4 * v->q;
 	h->last_shape[1] = v->rl;
@@ -89,15 +156,30 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	a.block_dwords = 0;
 	if (block_dwords) {
 		a.block_dwords = block_dwords;
-		if ((rc = h->scratch.reserve(blocks * team * block_dwords * sizeof(u32))))
+		// experiments: byte offsets (multiples of 256, up to 64 MiB) of the arenas / the hot region inside their allocations
+		const char *skew_e = getenv("POLAR_HIP_SCRATCH_SKEW"), *hskew_e = getenv("POLAR_HIP_HOT_SKEW");
+		const size_t slack = skew_e || hskew_e ? (size_t)64 << 20 : 0;
+		const size_t skew = skew_e ? (size_t)atol(skew_e) / 256 * 256 % (slack + 1) : 0, hskew = hskew_e ? (size_t)atol(hskew_e) / 256 * 256 % (slack + 1) : 0;
+		if (const char *e = getenv("POLAR_HIP_REALLOC")) { // experiments: free and allocate anew: "scratch", "hot" or "both"
+			HIP_TRY(hipStreamSynchronize(stream));
+			if (e[0] == 's' || e[0] == 'b')
+				h->scratch.release();
+			if (e[0] == 'h' || e[0] == 'b')
+				h->hot.release();
+		}
+		if (tune_placement && timed && direct && stream == h->stream)
+			placement_step(h, program_id, frames, v, blocks * team * block_dwords * sizeof(u32) + slack);
+		else
+			h->placement.pending = false;
+		if ((rc = h->scratch.reserve(blocks * team * block_dwords * sizeof(u32) + slack)))
 			return rc;
-		a.scratch = (u32 *)h->scratch.p;
+		a.scratch = (u32 *)((char *)h->scratch.p + skew);
 		a.hot_top = hot_top_for(v, lp.host.top, blocks * team);
 		if (a.hot_top > v->rl) { // the wavefronts' hot levels side by side in one compact region
 			a.hot_dwords = ((size_t)v->q << (a.hot_top + 1)) - ((size_t)v->q << (v->rl + 1));
-			if ((rc = h->hot.reserve(blocks * team * a.hot_dwords * sizeof(u32))))
+			if ((rc = h->hot.reserve(blocks * team * a.hot_dwords * sizeof(u32) + slack)))
 				return rc;
-			a.hot = (u32 *)h->hot.p;
+			a.hot = (u32 *)((char *)h->hot.p + hskew);
 		}
 	}
 	a.prof = nullptr;
@@ -117,7 +199,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 		static unsigned long long host[16 * 32 * 2];
 		HIP_TRY(hipMemcpyAsync(host, prof_dev, sizeof(host), hipMemcpyDeviceToHost, stream));
 		HIP_TRY(hipStreamSynchronize(stream));
-		static const char *names[16] = {"left", "right", "comb", "rate0", "rate1", "rep", "spc", "r0right", "r0comb", "r1comb", "?", "chain1", "chain2", "chain3", "chain4", "?"};
+		static const char *names[16] = {"left", "right", "comb", "rate0", "rate1", "rep", "spc", "r0right", "r0comb", "r1comb", "?", "chain1", "chain2", "chain3", "chain4", "subtree"};
 		unsigned long long total = 0;
 		for (int i = 0; i < 16 * 32; ++i)
 			total += host[2 * i];
@@ -132,6 +214,8 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	if (timed) {
 		HIP_TRY(hipEventRecord(h->ev1, stream));
 		h->timed = true;
+		if (tune_placement && direct && stream == h->stream && h->placement.program == program_id && !h->placement.done)
+			h->placement.pending = true;
 	}
 	if (!direct && rows)
 		HIP_TRY(hipMemcpy2DAsync(message, frames, msg, padded, frames, rows, hipMemcpyDeviceToDevice, stream));

@@ -70,11 +70,20 @@ struct polar_hip_handle {
 		bool operator<(const CodeKey &o) const { return level != o.level ? level < o.level : K != o.K ? K < o.K : p < o.p; }
 	};
 	std::map<CodeKey, CachedCode> codes; // polar_hip_code: (level, K, p) -> frozen set, program, resident id
-	DeviceBuffer scratch, hot, stage_in, stage_out, enc_tmp, tables, counters, pad_in, pad_out;
+	DeviceBuffer scratch, scratch_spare, hot, stage_in, stage_out, enc_tmp, tables, counters, pad_in, pad_out;
 	DeviceBuffer sim_cw, sim_llr, sim_msg, sim_dec; // polar_hip_simulate's chunk
 	DeviceBuffer f32_a, f32_b;                      // float path: LLRs / decisions of a chunk, symbol conversions
 	std::vector<uint8_t> frozen_cache; // frozen set the device tables were built from
 	int cfg_frames_per_wave = 0, cfg_lds_level = 0, cfg_team = 1, cfg_max_waves = 0;
+	// Placement of the scratch arenas (decode_launch.hpp, placement_step): the workload being watched,
+	// the kernel times of the placements tried so far, and whether the last launch is still to be read
+	struct Placement {
+		int program = -1, tries = 0;
+		size_t frames = 0, bytes = 0;
+		const void *fn = nullptr;
+		float best_ms = 0;
+		bool pending = false, done = false;
+	} placement;
 	int last_shape[3] = {0, 0, 0}; // frames per wavefront, LDS level, team of the last decode launch
 };
 
@@ -257,6 +266,7 @@ extern "C" void polar_hip_destroy(polar_hip_handle *h)
 	h->counters.release();
 	h->pad_in.release();
 	h->hot.release();
+	h->scratch_spare.release();
 	h->pad_out.release();
 	h->f32_a.release();
 	h->f32_b.release();

@@ -1730,7 +1730,7 @@ struct Group {
 			__builtin_amdgcn_s_waitcnt(0);
 			unsigned long long dt_ = __builtin_amdgcn_s_memtime() - t0_;
 			if (prof && (threadIdx.x & 63) == 0) {
-				u32 slot = ((op == OP_CHAIN ? 10 + chain_depth(pad) : op) * 32 + (u32)lvl) * 2;
+				u32 slot = ((op == OP_CHAIN ? 10 + chain_depth(pad) : op == OP_SUBTREE ? 15 : op) * 32 + (u32)lvl) * 2;
 				atomicAdd(&prof[slot], dt_);
 				atomicAdd(&prof[slot + 1], 1ull);
 			}

@@ -755,3 +755,45 @@ def test_bench_joins_the_rccl_group_as_a_world_of_one():
     assert r.returncode == 0, r.stdout + r.stderr
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
+
+
+def test_arena_placement_choice_keeps_results(oracle, golden, capfd, monkeypatch):
+    """decode_launch.hpp, placement_step: a handle that decodes the same resident batch repeatedly looks at
+    several placements of its scratch arenas (sets the current one aside, allocates another, keeps the
+    faster). Every call, on whichever arenas it runs, must return the reference's digest; the log shows
+    that placements were compared; another workload in between starts the comparison over and a batch
+    with small arenas is left alone."""
+    import polar_amd
+
+    meta, _ = golden
+    M, frames = 16, 1 << 17  # (64, 7) teams: 2048 arenas of 5 MiB
+    N = 1 << M
+    fro = _code(oracle, M)
+    prog = oracle.compile(fro, M)
+    k = [k for k in meta["decoder_digests"] if k["M"] == M][0]
+    cw = oracle.encode(pm1_message(k["msg_seed"], N // 2, k["frames"]), fro, M, 1)
+    llr = family_llr(k["family"], k["llr_seed"], cw)
+    wide = torch.from_numpy(llr).cuda().repeat(1, frames // 32).contiguous()
+    small = wide[:, :256].contiguous()
+    monkeypatch.setenv("POLAR_HIP_DEBUG", "1")
+    sess = polar_amd.Session(0)
+    dec = polar_amd.PolarDecoder(sess)
+    out = torch.empty((N // 2, frames), dtype=torch.int8, device="cuda")
+    out_small = torch.empty((N // 2, 256), dtype=torch.int8, device="cuda")
+
+    def check(o, f):
+        blocks = o.view(N // 2, f // 32, 32)
+        assert bool((blocks == blocks[:, :1, :]).all())
+        assert "%016x" % fnv1a64(o[:, :32].contiguous().cpu().numpy()) == k["out_fnv"]
+
+    for call in range(7):
+        out.fill_(55)
+        dec(out, wide, prog)
+        check(out, frames)
+        if call == 2:  # another workload between two calls: small arenas, no comparison, and the big one starts over
+            out_small.fill_(55)
+            dec(out_small, small, prog)
+            check(out_small, 256)
+    log = capfd.readouterr().err
+    assert log.count("arena placement") >= 4 and "arena placement 1:" in log, log[-2000:]
+    sess.close()

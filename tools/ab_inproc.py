@@ -18,6 +18,8 @@ ap.add_argument("--frames", default="1048576")
 ap.add_argument("--pads", default="0", help="POLAR_HIP_ARENA_PAD values (dwords)")
 ap.add_argument("--hot", default="", help="POLAR_HIP_HOT_LEVELS values (needs a build that reads it per launch)")
 ap.add_argument("--strides", default="0", help="extra bytes per row (POLAR_HIP_ROW_STRIDE = frames + this), multiples of 16")
+ap.add_argument("--skews", default="", help="POLAR_HIP_SCRATCH_SKEW values (bytes)")
+ap.add_argument("--hot-skews", default="", help="POLAR_HIP_HOT_SKEW values (bytes)")
 ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--snr", type=float, default=-1.0)
 a = ap.parse_args()
@@ -46,6 +48,12 @@ for r in range(0, N * maxf, step):
 out = torch.empty((N // 2) * maxf, dtype=torch.int8, device="cuda")
 dec = polar_amd.PolarDecoder(sess)
 os.environ["POLAR_HIP_ARENA_PAD"] = str(max(pads))  # the largest arena first: later launches fit, nothing is re-allocated
+skews = [int(x) for x in a.skews.split(",")] if a.skews else [None]
+hskews = [int(x) for x in a.hot_skews.split(",")] if a.hot_skews else [None]
+if skews[0] is not None:
+    os.environ["POLAR_HIP_SCRATCH_SKEW"] = "0"
+if hskews[0] is not None:
+    os.environ["POLAR_HIP_HOT_SKEW"] = "0"
 f0 = max(frames)
 dec(out[: (N // 2) * f0].view(N // 2, f0), flat[: N * f0].view(N, f0), prog)
 for rnd in range(a.rounds):
@@ -56,7 +64,13 @@ for rnd in range(a.rounds):
         else:
             os.environ.pop("POLAR_HIP_ROW_STRIDE", None)
         for pad in pads:
+          for sk in skews:
+           for hsk in hskews:
             os.environ["POLAR_HIP_ARENA_PAD"] = str(pad)
+            if sk is not None:
+                os.environ["POLAR_HIP_SCRATCH_SKEW"] = str(sk)
+            if hsk is not None:
+                os.environ["POLAR_HIP_HOT_SKEW"] = str(hsk)
             llr = flat[: N * f].view(N, f)
             o = out[: (N // 2) * f].view(N // 2, f)
             ms = []
@@ -64,4 +78,4 @@ for rnd in range(a.rounds):
                 dec(o, llr, prog)
                 ms.append(sess.last_decode_ms())
             best = min(ms)
-            print("round %d frames %d row +%d pad %d: kernel_ms %.2f  %.1f Gbit/s info  (%.3f us per frame)" % (rnd, f, extra, pad, best, f * (N // 2) / best / 1e6, best * 1e3 / f), flush=True)
+            print("round %d frames %d row +%d pad %d skew %s hot skew %s: kernel_ms %.2f  %.1f Gbit/s info  (%.3f us per frame)" % (rnd, f, extra, pad, sk, hsk, best, f * (N // 2) / best / 1e6, best * 1e3 / f), flush=True)
