@@ -59,7 +59,7 @@ static void placement_step(polar_hip_handle *h, int program_id, size_t frames, c
 	}
 	++t.tries;
 	std::swap(h->scratch, h->scratch_spare); // set the best aside; the reserve that follows allocates the candidate
-	if (h->scratch.reserve(bytes) != POLAR_OK) { // no room after all: go on with what we have
+	if (h->scratch.reserve_arenas(bytes, h->device) != POLAR_OK) { // no room after all: go on with what we have
 		(void)hipGetLastError();
 		std::swap(h->scratch, h->scratch_spare);
 		t.done = true;
@@ -171,7 +171,13 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 			placement_step(h, program_id, frames, v, blocks * team * block_dwords * sizeof(u32) + slack);
 		else
 			h->placement.pending = false;
-		if ((rc = h->scratch.reserve(blocks * team * block_dwords * sizeof(u32) + slack)))
+		// experiments: POLAR_HIP_ARENA_PIECES = "<MiB per piece>[s]": the arenas as separately allocated pieces of
+		// device memory mapped into one range, in a shuffled order with an 's', the range aligned to the piece size with an 'a'
+		if (const char *pe = getenv("POLAR_HIP_ARENA_PIECES")) {
+			if (atoi(pe) > 0 && !strchr(pe, 'd') && (rc = h->scratch.reserve_chunked(blocks * team * block_dwords * sizeof(u32) + slack, (size_t)atoi(pe) << 20, strchr(pe, 's') != nullptr, h->device, strchr(pe, 'a') != nullptr)))
+				return rc;
+		}
+		if ((rc = h->scratch.reserve_arenas(blocks * team * block_dwords * sizeof(u32) + slack, h->device)))
 			return rc;
 		a.scratch = (u32 *)((char *)h->scratch.p + skew);
 		a.hot_top = hot_top_for(v, lp.host.top, blocks * team);

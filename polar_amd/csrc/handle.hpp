@@ -17,22 +17,119 @@ static void *g_static_scratch[MAX_DEVICES];
 struct DeviceBuffer {
 	void *p = nullptr;
 	size_t bytes = 0;
+	// chunked form (reserve_chunked): one virtual range backed by separately allocated pieces of device
+	// memory, mapped in a shuffled order (hipMemCreate / hipMemMap)
+	std::vector<hipMemGenericAllocationHandle_t> pieces;
+	size_t piece_bytes = 0;
 	int reserve(size_t want)
 	{
 		if (want <= bytes)
 			return POLAR_OK;
-		if (p)
-			(void)hipFree(p);
-		p = nullptr;
-		bytes = 0;
+		release();
 		HIP_TRY(hipMalloc(&p, want));
 		bytes = want;
 		return POLAR_OK;
 	}
+	// `want` bytes as pieces of `piece` bytes each, piece i of the range backed by allocation perm(i):
+	// a fixed pseudo-random order when `shuffle`, else the order of allocation
+	int reserve_chunked(size_t want, size_t piece, bool shuffle, int device, bool align = false)
+	{
+		if (want <= bytes)
+			return POLAR_OK;
+		release();
+		hipMemAllocationProp prop = {};
+		prop.type = hipMemAllocationTypePinned;
+		prop.location.type = hipMemLocationTypeDevice;
+		prop.location.id = device;
+		size_t gran = 0;
+		HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+		if (!gran)
+			gran = (size_t)2 << 20;
+		piece = (piece + gran - 1) / gran * gran;
+		const size_t count = (want + piece - 1) / piece, total = count * piece;
+		void *base = nullptr;
+		// `align`: the range starts on a multiple of the piece size (a power of two then), so that a piece the driver
+		// hands out aligned to its size can be mapped with one large translation
+		HIP_TRY(hipMemAddressReserve(&base, total, align && !(piece & (piece - 1)) ? piece : 0, nullptr, 0));
+		p = base;
+		bytes = total;
+		piece_bytes = piece;
+		pieces.reserve(count);
+		for (size_t i = 0; i < count; ++i) {
+			hipMemGenericAllocationHandle_t hnd;
+			hipError_t e = hipMemCreate(&hnd, piece, &prop, 0);
+			if (e != hipSuccess) {
+				release();
+				HIP_TRY(e);
+			}
+			pieces.push_back(hnd);
+		}
+		std::vector<size_t> perm(count);
+		for (size_t i = 0; i < count; ++i)
+			perm[i] = i;
+		if (shuffle) { // Fisher-Yates with a fixed LCG: the same order every time
+			uint64_t x = 0x9E3779B97F4A7C15ull;
+			for (size_t i = count - 1; i > 0; --i) {
+				x = x * 6364136223846793005ull + 1442695040888963407ull;
+				std::swap(perm[i], perm[(size_t)((x >> 33) % (i + 1))]);
+			}
+		}
+		mapped = 0;
+		for (size_t i = 0; i < count; ++i) {
+			hipError_t e = hipMemMap((char *)base + i * piece, piece, 0, pieces[perm[i]], 0);
+			if (e != hipSuccess) {
+				release();
+				HIP_TRY(e);
+			}
+			mapped = i + 1;
+		}
+		hipMemAccessDesc acc = {};
+		acc.location = prop.location;
+		acc.flags = hipMemAccessFlagsProtReadWrite;
+		hipError_t e = hipMemSetAccess(base, total, &acc, 1);
+		if (e != hipSuccess) {
+			release();
+			HIP_TRY(e);
+		}
+		return POLAR_OK;
+	}
+	// The wavefront arenas. From 2 GiB on: pieces of 1 GiB, each allocated on its own and mapped at a multiple
+	// of 1 GiB of one virtual range. A plain hipMalloc of the same size lands, about every other time, on
+	// memory that costs the decode kernel 5 % (231 instead of 219 ms for 2^20 frames of N = 2^16, the same
+	// virtual address both times); with pieces that the driver hands out aligned to their size and that are
+	// mapped equally aligned, four allocations in four gave 218-222 ms (profiles/r3_placement_pieces.txt;
+	// pieces of 2-8 MiB in a shuffled order: always the slow 232 ms, which points at the size of the address
+	// translations). Falls back to hipMalloc where the virtual-memory calls are refused.
+	// POLAR_HIP_ARENA_PIECES=0 forces the plain allocation.
+	int reserve_arenas(size_t want, int device)
+	{
+		if (want <= bytes)
+			return POLAR_OK;
+		static const bool plain = getenv("POLAR_HIP_ARENA_PIECES") && atoi(getenv("POLAR_HIP_ARENA_PIECES")) == 0;
+		if (!plain && want >= ((size_t)2 << 30)) {
+			if (reserve_chunked(want, (size_t)1 << 30, false, device, true) == POLAR_OK)
+				return POLAR_OK;
+			(void)hipGetLastError();
+			release();
+		}
+		return reserve(want);
+	}
+	size_t mapped = 0;
 	void release()
 	{
-		if (p)
+		if (piece_bytes) {
+			for (size_t i = 0; i < mapped; ++i)
+				(void)hipMemUnmap((char *)p + i * piece_bytes, piece_bytes);
+			for (auto hnd : pieces)
+				(void)hipMemRelease(hnd);
+			if (p)
+				(void)hipMemAddressFree(p, bytes);
+			pieces.clear();
+			piece_bytes = 0;
+			mapped = 0;
+		} else if (p) {
 			(void)hipFree(p);
+		}
 		p = nullptr;
 		bytes = 0;
 	}
