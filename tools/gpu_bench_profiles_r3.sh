@@ -1,7 +1,7 @@
 #!/bin/bash
 # bench lines + rocprofv3 evidence for configs B (headline), A, D and E on the final library
 export TMPDIR=/tmp
-mkdir -p gpurun_out
+mkdir -p gpurun_out/prof_r3_E
 bash tools/prof_bench.sh r3_B || exit 1
 bash tools/prof_bench.sh r3_A --config A || exit 1
 bash tools/prof_bench.sh r3_D --config D || exit 1
