@@ -80,7 +80,7 @@ def parse(argv=None):
     ap.add_argument("--plumbing-only", action="store_true", help=argparse.SUPPRESS)  # CPU/gloo test of the rank plumbing
     ap.add_argument("--rank-timeout", type=float, default=1500.0, help="seconds the rank launcher waits for its children")
     ap.add_argument("--init-timeout", type=float, default=180.0, help="seconds a rank waits in the process-group rendezvous")
-    ap.add_argument("--streams", type=int, default=4, help="config E: handles / HIP streams the launch set is spread over (1 = back to back)")
+    ap.add_argument("--streams", type=int, default=0, help="config E: 0 = the library's polar_hip_decode_set (four internal lanes); k > 0 = k handles / HIP streams managed here (1 = back to back; experiments)")
     ap.add_argument("--lane-waves", type=int, default=0, help="config E: resident wavefronts per handle (0 = an equal share of the device)")
     ap.add_argument("--force-dist", action="store_true", help="join the RCCL process group even as a world of one (rehearses the N > 1 path on a one-GPU box)")
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)  # test: this rank exits 3 at start
@@ -556,41 +556,52 @@ def run_config_e(torch, polar_amd, sess, args, rank, world, dev, dist):
     # resident wavefronts (polar_hip_configure max_waves: the shape is picked for that share), batch i
     # on lane i % lanes: batches of the large codes are few frames each and bound by the serial depth
     # of the program, so several of them side by side fill the device that one alone leaves idle.
-    lanes = max(1, args.streams)
+    use_set = args.streams <= 0
+    lanes = 4 if use_set else args.streams
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
-    sessions = [sess] + [polar_amd.Session(dev.index) for _ in range(lanes - 1)]
+    sessions = [sess] + ([] if use_set else [polar_amd.Session(dev.index) for _ in range(lanes - 1)])
     stride = int(os.environ.get("BENCH_STREAM_STRIDE", "1"))  # experiments: which of torch's pooled streams the lanes take
-    streams = [torch.cuda.Stream(device=dev) for _ in range(lanes * stride)][::stride]
+    streams = [] if use_set else [torch.cuda.Stream(device=dev) for _ in range(lanes * stride)][::stride]
     decs = [polar_amd.PolarDecoder(s) for s in sessions]
     if lanes > 1 and not args.fpw:
         for s in sessions:
             s.configure(0, 0, args.lane_waves or 8 * cus // lanes)
-    # placement: every batch decoded once alone on a share-sized handle, then longest first onto the
-    # lane with the least work so far (the lanes finish together; launch order within a lane = that order)
+    # every batch decoded once alone on a share-sized handle: the shape it gets, and (lanes managed here)
+    # its solo time for the placement: longest first onto the lane with the least work so far
     for j in jobs:
         decs[0](j["out"], j["llr"], j["prog"])
         j["solo_ms"] = sessions[0].last_decode_ms()
         j["shape"] = sessions[0].last_decode_shape()
+    if use_set and not args.fpw:
+        sess.configure(0, 0, 0)
     load = [0.0] * lanes
     order = sorted(range(len(jobs)), key=lambda i: -jobs[i]["solo_ms"])
-    for i in order:
-        k = load.index(min(load))
-        jobs[i]["lane"] = k
-        load[k] += jobs[i]["solo_ms"]
-        sessions[k].load_program(jobs[i]["prog"])
+    if not use_set:
+        for i in order:
+            k = load.index(min(load))
+            jobs[i]["lane"] = k
+            load[k] += jobs[i]["solo_ms"]
+            sessions[k].load_program(jobs[i]["prog"])
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    set_jobs = [(j["out"], j["llr"], j["prog"]) for j in jobs]
 
     def step():
         torch.cuda.synchronize(dev)
-        ev0.record(streams[0])
-        for st in streams[1:]:
-            st.wait_event(ev0)
-        for i in order:
-            j = jobs[i]
-            decs[j["lane"]].launch(j["out"], j["llr"], j["prog"], streams[j["lane"]].cuda_stream)
-        for st in streams[1:]:
-            streams[0].wait_stream(st)
-        ev1.record(streams[0])
+        if use_set:  # one library call: polar_hip_decode_set places and launches the batches on its lanes
+            cur = torch.cuda.current_stream(dev)
+            ev0.record(cur)
+            decs[0].decode_set(set_jobs)
+            ev1.record(cur)
+        else:
+            ev0.record(streams[0])
+            for st in streams[1:]:
+                st.wait_event(ev0)
+            for i in order:
+                j = jobs[i]
+                decs[j["lane"]].launch(j["out"], j["llr"], j["prog"], streams[j["lane"]].cuda_stream)
+            for st in streams[1:]:
+                streams[0].wait_stream(st)
+            ev1.record(streams[0])
         torch.cuda.synchronize(dev)
         kernel_ms.append(ev0.elapsed_time(ev1))  # GPU time of the whole launch set (the launches overlap)
         for j in jobs:
@@ -643,7 +654,7 @@ def run_config_e(torch, polar_amd, sess, args, rank, world, dev, dist):
             "kernel": "sc_decode kernels, one launch per batch; shape (frames per wavefront, LDS level, team) by N: " + ", ".join(
                 "2^%d: %s" % (M, tuple(shapes[M])) for M in sorted(shapes)),
             "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg,
-            "note": "one 'launch' here = the %d decode launches of a step, spread over %d HIP streams; kernel_ms = GPU time of the whole set (events on the launch streams)" % (len(jobs), lanes)}
+            "note": "one 'launch' here = the %d decode launches of a step, spread over %d HIP streams (%s); kernel_ms = GPU time of the whole set (events around it)" % (len(jobs), lanes, "polar_hip_decode_set" if use_set else "handles managed by bench.py")}
     if prof:
         roof["traffic_frac"] = prof["bytes_per_launch"] / (k_ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
         for key in ("valu_util", "lds_bw_util", "lds_bank_conflict_frac"):

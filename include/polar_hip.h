@@ -141,6 +141,22 @@ void polar_hip_host_free(void *ptr);
  * the latter waits for the device). Launches after that only enqueue. */
 int polar_hip_decode_async(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, void *stream);
 
+/* A set of resident batches of different codes and sizes decoded side by side (Eb/N0 sweeps with
+ * per-SNR frozen sets, mixed N = 2^10 .. 2^16 batches; each job = one PolarDecoder::operator() call of
+ * testbench.cc:171 on its own program). A batch of a large code holds few frames and is bound by the serial
+ * depth of its program: jobs that fill the device on their own are launched one after the other, all the
+ * others share one kernel launch whose workgroups are dealt to them so that they finish together; returns
+ * when all are done. Device pointers only; program ids as returned by
+ * polar_hip_load_program / polar_hip_code on `h`. No counterpart in the reference (one decoder, one call
+ * at a time). */
+typedef struct polar_hip_job {
+	int program_id;
+	int8_t *message;
+	const int8_t *codeword;
+	size_t frames;
+} polar_hip_job;
+int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jobs, int count);
+
 /* The float path of the reference: PolarDecoder<SIMD<float,W>,MAX_M>::operator() with
  * PolarHelper<SIMD<VALUE,WIDTH>> (polar_helper.hh:62-111), selected in the bench by
  * `typedef float code_type` (testbench.cc:49-53). codeword: N x frames float LLRs, message:

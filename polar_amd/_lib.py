@@ -32,6 +32,7 @@ SYMBOLS = {
     "polar_hip_host_alloc": ([_sz], _vp),
     "polar_hip_host_free": ([_vp], None),
     "polar_hip_decode_async": ([_vp, _i, _vp, _vp, _sz, _vp], _i),
+    "polar_hip_decode_set": ([_vp, _vp, _i], _i),
     "polar_hip_decode_f32": ([_vp, _i, _vp, _vp, _sz, _i], _i),
     "polar_hip_encode_f32": ([_vp, _i, _vp, _vp, _vp, _i, _sz, _i], _i),
     "polar_hip_channel_f32": ([_vp, _vp, _vp, _sz, _sz, ctypes.c_double, ctypes.c_uint64, ctypes.c_uint64, _i], _i),

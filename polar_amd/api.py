@@ -302,6 +302,28 @@ class PolarDecoder:
             return
         _check(lib.polar_hip_decode(self.session._h, pid, mp, cp, frames, _where(mw, cw)), "PolarDecoder")
 
+    def decode_set(self, jobs):
+        """polar_hip_decode_set: jobs = [(message, codeword, program), ...], device tensors of any mix of codes
+        and batch sizes, decoded side by side on the handle's internal lanes; returns when all are done."""
+
+        class Job(ctypes.Structure):
+            _fields_ = [("program_id", ctypes.c_int), ("message", ctypes.c_void_p), ("codeword", ctypes.c_void_p), ("frames", ctypes.c_size_t)]
+
+        arr = (Job * len(jobs))()
+        for i, (message, codeword, program) in enumerate(jobs):
+            pid, rows = self.session.load_program(program)
+            n = 1 << int(np.asarray(program).ravel()[0])
+            frames = _frames(codeword)
+            if codeword.shape[0] != n or (rows and (message.shape[0] < rows or _frames(message) != frames)):
+                raise ValueError("job %d: buffer shapes do not match the program" % i)
+            (mp, mw), (cp, cw) = _ptr(message), _ptr(codeword)
+            if _where(mw, cw) != DEVICE:
+                raise ValueError("job %d: the batches of a set are device tensors" % i)
+            arr[i] = Job(pid, mp.value, cp.value, frames)
+        if jobs:
+            self.session._order(jobs[0][1])
+        _check(lib.polar_hip_decode_set(self.session._h, ctypes.cast(arr, ctypes.c_void_p), len(jobs)), "PolarDecoder.decode_set")
+
     def launch(self, message, codeword, program, stream):
         """Enqueue on a HIP stream without synchronising (device buffers only)."""
         pid, _ = self.session.load_program(program)

@@ -82,7 +82,7 @@ extern "C" int polar_hip_decode_static(polar_hip_handle *h, int program_id, int8
 	if (groups > 0x7FFFFFFFu)
 		return fail(POLAR_E_ARG, "too many frames for one call");
 	size_t blocks = (size_t)occ->second * h->cus; // workgroups of `team` wavefronts
-	DecodeArgs a;
+	DecodeArgs a = {};
 	a.scratch = nullptr;
 	a.block_dwords = 0;
 	if (lp.host.top > v->rl) {

@@ -22,6 +22,12 @@ struct DecodeArgs {
 	u32 *hot;              // ... and live here: one block of hot_dwords per wavefront, side by side
 	size_t hot_dwords;     // (Q << (hot_top + 1)) - (Q << (RL + 1)), 0 when there is no hot level
 	unsigned long long *prof; // diagnostic build (POLAR_PROFILE) only
+	// a set of jobs in one launch (team kernels, polar_hip_decode_set): `set` = set_jobs + 1 entries of this
+	// struct in device memory, entry j = the arguments of job j and set_first = its first workgroup; the last
+	// entry only carries the total. 0 jobs: an ordinary launch.
+	const DecodeArgs *set;
+	u32 set_jobs;
+	u32 set_first;
 };
 
 // Persistent wavefronts: block b walks the groups b, b + gridDim, ... Blocks are dealt to
@@ -72,7 +78,31 @@ __global__ void __launch_bounds__(64 * TEAM_WAVES, 2) sc_decode_team_kernel(Deco
 {
 	typedef Group<Q, RL, true> G;
 	__shared__ __attribute__((aligned(16))) u32 lds[TEAM_WAVES * G::LDS_DWORDS];
-	const u32 nb = gridDim.x, b = blockIdx.x, w = threadIdx.x >> 6;
+	u32 nb = gridDim.x, b = blockIdx.x;
+	const u32 w = threadIdx.x >> 6;
+	if (a.set_jobs) {
+		// One launch, several jobs (codes, batch sizes): this workgroup is workgroup b - first of the
+		// next - first that job j was given, and runs on job j's arguments (scalar loads, like the program).
+		typedef const __attribute__((address_space(4))) DecodeArgs *table_ptr;
+		const table_ptr tab = (table_ptr)a.set;
+		u32 j = 0;
+		for (u32 k = 1; k < a.set_jobs; ++k)
+			j += b >= tab[k].set_first;
+		const u32 first = tab[j].set_first;
+		nb = tab[j + 1].set_first - first;
+		b -= first;
+		a.prog = tab[j].prog;
+		a.cw = tab[j].cw;
+		a.msg = tab[j].msg;
+		a.scratch = tab[j].scratch;
+		a.block_dwords = tab[j].block_dwords;
+		a.stride = tab[j].stride;
+		a.groups = tab[j].groups;
+		a.top = tab[j].top;
+		a.hot_top = RL;
+		a.hot = nullptr;
+		a.hot_dwords = 0;
+	}
 	const u32 slot = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
 	u32 *arena = a.scratch ? a.scratch + ((size_t)b * TEAM_WAVES + w) * a.block_dwords : nullptr;
 	const size_t plane = ((size_t)Q << a.top) / 8;

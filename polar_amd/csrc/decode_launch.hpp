@@ -139,7 +139,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	h->last_shape[0] = 4 * v->q;
 	h->last_shape[1] = v->rl;
 	h->last_shape[2] = v->team;
-	DecodeArgs a;
+	DecodeArgs a = {};
 	a.prog = lp.dev[shape];
 	a.cw = cw;
 	a.msg = msg;

@@ -181,6 +181,7 @@ struct polar_hip_handle {
 		float best_ms = 0;
 		bool pending = false, done = false;
 	} placement;
+	DeviceBuffer set_table; // polar_hip_decode_set: the argument table of the common launch
 	int last_shape[3] = {0, 0, 0}; // frames per wavefront, LDS level, team of the last decode launch
 };
 
@@ -349,6 +350,7 @@ extern "C" void polar_hip_destroy(polar_hip_handle *h)
 	(void)hipStreamSynchronize(h->stream);
 	if (h->stream != h->own_stream)
 		(void)hipStreamSynchronize(h->own_stream);
+	h->set_table.release();
 	for (auto &p : h->programs) {
 		for (auto &d : p.dev)
 			(void)hipFree(d.second);

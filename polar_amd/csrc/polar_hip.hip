@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <thread>
@@ -92,6 +93,7 @@ static const KernelVariant *find_variant(int q, int rl, int team = 1)
 #include "decode_launch.hpp"
 #include "host_pipeline.hpp"
 #include "abi_decode.hpp"
+#include "abi_set.hpp"
 #include "abi_encode.hpp"
 #include "abi_simulate.hpp"
 #include "abi_float.hpp"

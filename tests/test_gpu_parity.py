@@ -696,6 +696,41 @@ def test_mixed_sizes_in_one_launch_set(session, oracle):
     stream.synchronize()
     for prog, llr, _d, d_out in jobs:
         assert (d_out.cpu().numpy() == oracle.decode(llr, prog)).all(), int(prog[0])
+    # the same set through polar_hip_decode_set: the library spreads the jobs over its four lanes; twice, the
+    # second time with the jobs in another order and one of them empty
+    for rnd in range(2):
+        for _p, _l, _d, d_out in jobs:
+            d_out.fill_(9)
+        sel = jobs if rnd == 0 else jobs[::-1]
+        set_jobs = [(d_out, d_llr, prog) for prog, _llr, d_llr, d_out in sel]
+        if rnd:
+            N = 1 << 10
+            set_jobs.append((torch.zeros((N // 2, 0), dtype=torch.int8, device="cuda"), torch.zeros((N, 0), dtype=torch.int8, device="cuda"), jobs[0][0]))
+        dec.decode_set(set_jobs)
+        for prog, llr, _d, d_out in jobs:
+            assert (d_out.cpu().numpy() == oracle.decode(llr, prog)).all(), (rnd, int(prog[0]))
+    # whole teams (multiples of 128 frames) of codes that do not fill the device share ONE kernel launch; a batch
+    # that does fill it (N = 2^10, 2^19 frames, checked by tiling) is launched on its own inside the same call
+    shared = []
+    for k, M in enumerate(range(10, 15)):
+        N = 1 << M
+        fro, _ = oracle.const0(M, N // 2, float(np.exp(-(10.0 ** ((-1.0 + 0.3 * k) / 10.0)))))
+        prog = oracle.compile(fro, M)
+        frames = 128 * (1 + (k * 2) % 5)
+        msg = oracle.random_message(N // 2, frames, 300 + M)
+        llr = oracle.channel(oracle.encode(msg, fro, M, 1), -1.0, 400 + M)
+        shared.append((prog, llr, torch.from_numpy(llr).cuda(), torch.full((N // 2, frames), 9, dtype=torch.int8, device="cuda")))
+    prog0, llr0 = shared[0][0], shared[0][1][:, :32]
+    big_in = torch.from_numpy(np.ascontiguousarray(llr0)).cuda().repeat(1, (1 << 19) // 32).contiguous()
+    big_out = torch.full((512, 1 << 19), 9, dtype=torch.int8, device="cuda")
+    dec.decode_set([(d_out, d_llr, prog) for prog, _llr, d_llr, d_out in shared] + [(big_out, big_in, prog0)])
+    for prog, llr, _d, d_out in shared:
+        assert (d_out.cpu().numpy() == oracle.decode(llr, prog)).all(), ("shared launch", int(prog[0]))
+    exp0 = torch.from_numpy(oracle.decode(np.ascontiguousarray(llr0), prog0)).cuda()
+    assert bool((big_out.view(512, -1, 32) == exp0.view(512, 1, 32)).all())
+    del big_in, big_out
+    with pytest.raises(ValueError):
+        dec.decode_set([(np.zeros((512, 4), np.int8), np.zeros((1024, 4), np.int8), jobs[0][0])])  # host buffers are refused
 
 
 def test_cpp_dropin_header():
