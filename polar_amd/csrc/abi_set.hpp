@@ -5,8 +5,8 @@
 // (8.9 ms for 8 192 frames of N = 2^16 whatever the kernel shape), so one such launch leaves most of the
 // device idle. polar_hip_decode_set (per-SNR frozen sets, mixed N = 2^10 .. 2^16 batches) sorts
 // its jobs in two: those that fill the device on their own (the default pick is the widest shape) are
-// launched one after the other as polar_hip_decode would; all the others share ONE launch of the (32, 8)
-// team kernel, whose workgroups are dealt to the jobs so that all of them finish together: a job of
+// launched one after the other as polar_hip_decode would; all the others share ONE launch of a team kernel
+// ((64, 7) or (32, 8), see below), whose workgroups are dealt to the jobs so that all of them finish together: a job of
 // `units` teams that gets `blocks` workgroups takes ceil(units / blocks) walks of its program, a walk is
 // about N / 16 device operations of 2 us, and the smallest common finishing time for which the workgroups
 // add up to the resident ones is found by bisection. One launch on one queue: several launches on streams
@@ -29,9 +29,33 @@ extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jo
 		if (jobs[i].frames && (polar_hip_where(jobs[i].codeword) != POLAR_DEVICE || (h->programs[jobs[i].program_id].host.rows && polar_hip_where(jobs[i].message) != POLAR_DEVICE)))
 			return fail(POLAR_E_ARG, "polar_hip_decode_set: the batches of a set are device-resident (device pointers only)");
 	}
-	const KernelVariant *v = find_variant(SET_Q, SET_RL, SET_TEAM);
+	// the common launch: (64, 7) teams when the jobs that will share it bring at least one team per resident
+	// workgroup (8 % faster than (32, 8) teams under load: config E 118 -> 127 Gbit/s), else (32, 8) teams (more,
+	// narrower teams for a set that is short of frames altogether)
+	int set_q = SET_Q, set_rl = SET_RL;
+	{
+		size_t wide_teams = 0;
+		bool whole = true;
+		for (int i = 0; i < count; ++i) {
+			if (!jobs[i].frames || h->cfg_frames_per_wave)
+				continue;
+			ScratchBudget budget{h};
+			const KernelVariant *own = pick_variant(h, h->programs[jobs[i].program_id].host.top, jobs[i].frames, budget);
+			if (own && own->q == 32)
+				continue; // fills the device on its own
+			whole = whole && jobs[i].frames % 256 == 0;
+			wide_teams += jobs[i].frames / 256;
+		}
+		if (whole && wide_teams >= (size_t)2 * h->cus && find_variant(16, 7, SET_TEAM)) {
+			set_q = 16;
+			set_rl = 7;
+		}
+	}
+	if (const char *e = getenv("POLAR_HIP_SET_SHAPE")) // experiments: "8,8" or "16,7"
+		sscanf(e, "%d,%d", &set_q, &set_rl);
+	const KernelVariant *v = find_variant(set_q, set_rl, SET_TEAM);
 	std::vector<int> shared; // jobs of the common launch
-	const size_t fpw = 4 * (size_t)SET_Q * SET_TEAM;
+	const size_t fpw = 4 * (size_t)set_q * SET_TEAM;
 	for (int i = 0; i < count; ++i) {
 		if (!jobs[i].frames)
 			continue;
@@ -40,7 +64,7 @@ extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jo
 		const KernelVariant *own = h->cfg_frames_per_wave ? nullptr : pick_variant(h, lp.host.top, jobs[i].frames, budget);
 		const bool direct = jobs[i].frames % fpw == 0 && (uintptr_t)jobs[i].codeword % 16 == 0 && (uintptr_t)jobs[i].message % 16 == 0;
 		const bool fills = !own || own->q == 32; // a configured shape, or the widest one: the job is not short of frames
-		if (v && direct && !fills && lp.host.top > SET_RL)
+		if (v && direct && !fills && lp.host.top > set_rl)
 			shared.push_back(i);
 		else if ((rc = launch_decode(h, jobs[i].program_id, jobs[i].message, jobs[i].codeword, jobs[i].frames, h->stream, false)))
 			return rc;
@@ -110,7 +134,7 @@ extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jo
 			LoadedProgram &lp = h->programs[jobs[shared[k]].program_id];
 			if ((rc = upload_shape(lp, v)))
 				return rc;
-			const size_t soft = (size_t)SET_Q << lp.host.top, block_dwords = soft + 2 * (soft / 8);
+			const size_t soft = (size_t)set_q << lp.host.top, block_dwords = soft + 2 * (soft / 8);
 			DecodeArgs &t = table[k];
 			t = DecodeArgs{};
 			t.prog = lp.dev[program_shape(v)];
@@ -120,7 +144,7 @@ extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jo
 			t.stride = jobs[shared[k]].frames;
 			t.groups = (u32)(units[k] * SET_TEAM);
 			t.top = lp.host.top;
-			t.hot_top = SET_RL;
+			t.hot_top = set_rl;
 			t.set_first = (u32)first;
 			t.scratch = (u32 *)(uintptr_t)arena_dwords; // offset for now: the base is known after the reserve
 			arena_dwords += blocks[k] * SET_TEAM * block_dwords;
