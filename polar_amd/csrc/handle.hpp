@@ -547,24 +547,39 @@ static const KernelVariant *pick_variant(const polar_hip_handle *h, int top, siz
 {
 	if (h->cfg_frames_per_wave)
 		return find_variant(h->cfg_frames_per_wave / 4, h->cfg_lds_level, h->cfg_team);
-	// Measured (tools/gpu_sweep_pick.sh, tools/gpu_team*.sh): a wavefront walks
-	// the program in about the same time whatever its width, so the widest group wins as soon as
-	// every resident wavefront has one -- two for 128 frames, whose one-sweep batches the 64-frame
-	// teams decode faster; groups of 32 frames already pay off when three eighths of the wavefronts
-	// have one, narrower ones when half of them do. Groups of 32 and 64 frames go in teams of four (whole 128-byte input lines).
-	// a handle limited to a share of the device (polar_hip_configure: max_waves; several handles decoding
-	// side by side on their own streams) picks its shape for that share
+	// A wavefront walks the program in about the same time whatever its width, a little longer the busier the
+	// device is. Per shape: its walk time on a lightly and on a fully loaded device, relative, measured at
+	// N = 2^16 (profiles/r3_pick_sweep.txt; the ratios hold for the other code sizes). A batch of `units` groups
+	// (teams) on `cap` resident ones takes ceil(units / cap) sweeps of one walk each at load units / (sweeps * cap).
+	// The shape with the shortest time by this model wins; a narrower one must win by 3 % (steady multi-sweep
+	// batches favour the wide shape's hot levels a little more than the one-sweep figures say).
+	// Groups of 32 and 64 frames go in teams of four (whole 128-byte input lines).
+	// A handle limited to a share of the device (polar_hip_configure: max_waves; several handles decoding
+	// side by side on their own streams) picks its shape for that share.
 	size_t resident = (size_t)8 * h->cus;
 	if (h->cfg_max_waves && (size_t)h->cfg_max_waves < resident)
 		resident = (size_t)h->cfg_max_waves;
-	static const int family[][3] = {{32, 6, 1}, {16, 7, 4}, {8, 8, 4}, {4, 9, 1}, {2, 10, 1}, {1, 11, 1}};
+	// walk = light + (full - light) * load^bend: the wide shapes slow down in proportion to the load (bandwidth),
+	// the narrow ones stay near their latency floor until the device is nearly full
+	static const struct { int q, rl, team; double light, full; int bend; } family[] = {
+		{32, 6, 1, 27.0, 57.0, 1}, {16, 7, 4, 17.3, 29.1, 1}, {8, 8, 4, 10.8, 16.9, 2}, {4, 9, 1, 7.3, 14.8, 2}, {2, 10, 1, 7.0, 10.8, 2}, {1, 11, 1, 7.0, 9.4, 2}};
+	const KernelVariant *best = nullptr;
+	double best_t = 0;
 	for (const auto &f : family) {
-		size_t groups = (frames + 4 * f[0] - 1) / (4 * f[0]);
-		if (f[0] > 1 && groups < (f[0] == 32 ? 2 * resident : f[0] == 8 ? resident * 3 / 8 : f[0] < 8 ? resident / 2 : resident))
+		const KernelVariant *v = find_variant(f.q, f.rl, f.team);
+		if (!v)
 			continue;
-		if (f[0] > 1 && top > f[1] && !budget.fits(resident * scratch_bytes_per_wave(f[0], top)))
-			continue;
-		return find_variant(f[0], f[1], f[2]);
+		if (f.q > 1 && top > f.rl && !budget.fits(resident * scratch_bytes_per_wave(f.q, top)))
+			continue; // the arenas of a full device would not fit: a narrower shape (fewer resident wavefronts as the last resort)
+		const size_t unit = 4 * (size_t)f.q * f.team, units = (frames + unit - 1) / unit;
+		const size_t cap = resident / f.team ? resident / f.team : 1;
+		const size_t sweeps = (units + cap - 1) / cap;
+		const double load = (double)units / (double)(sweeps * cap);
+		const double t = (double)sweeps * (f.light + (f.full - f.light) * (f.bend == 2 ? load * load : load));
+		if (!best || t < best_t * 0.97) {
+			best = v;
+			best_t = t;
+		}
 	}
-	return nullptr;
+	return best;
 }
