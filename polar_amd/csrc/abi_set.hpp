@@ -4,7 +4,7 @@
 // A batch of a large code holds few frames for its bytes and is bound by the serial depth of its program
 // (8.9 ms for 8 192 frames of N = 2^16 whatever the kernel shape), so one such launch leaves most of the
 // device idle. polar_hip_decode_set (per-SNR frozen sets, mixed N = 2^10 .. 2^16 batches) sorts
-// its jobs in two: those that fill the device on their own (the default pick is the widest shape) are
+// its jobs in two: those that fill the device on their own (two sweeps and more of 128-frame groups) are
 // launched one after the other as polar_hip_decode would; all the others share ONE launch of a team kernel
 // ((64, 7) or (32, 8), see below), whose workgroups are dealt to the jobs so that all of them finish together: a job of
 // `units` teams that gets `blocks` workgroups takes ceil(units / blocks) walks of its program, a walk is
@@ -39,9 +39,7 @@ extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jo
 		for (int i = 0; i < count; ++i) {
 			if (!jobs[i].frames || h->cfg_frames_per_wave)
 				continue;
-			ScratchBudget budget{h};
-			const KernelVariant *own = pick_variant(h, h->programs[jobs[i].program_id].host.top, jobs[i].frames, budget);
-			if (own && own->q == 32)
+			if (jobs[i].frames / 128 >= (size_t)16 * h->cus)
 				continue; // fills the device on its own
 			whole = whole && jobs[i].frames % 256 == 0;
 			wide_teams += jobs[i].frames / 256;
@@ -60,10 +58,9 @@ extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jo
 		if (!jobs[i].frames)
 			continue;
 		const LoadedProgram &lp = h->programs[jobs[i].program_id];
-		ScratchBudget budget{h};
-		const KernelVariant *own = h->cfg_frames_per_wave ? nullptr : pick_variant(h, lp.host.top, jobs[i].frames, budget);
 		const bool direct = jobs[i].frames % fpw == 0 && (uintptr_t)jobs[i].codeword % 16 == 0 && (uintptr_t)jobs[i].message % 16 == 0;
-		const bool fills = !own || own->q == 32; // a configured shape, or the widest one: the job is not short of frames
+		// a configured shape, or two sweeps and more of the widest one: the job is not short of frames
+		const bool fills = h->cfg_frames_per_wave || jobs[i].frames / 128 >= (size_t)16 * h->cus;
 		if (v && direct && !fills && lp.host.top > set_rl)
 			shared.push_back(i);
 		else if ((rc = launch_decode(h, jobs[i].program_id, jobs[i].message, jobs[i].codeword, jobs[i].frames, h->stream, false)))
