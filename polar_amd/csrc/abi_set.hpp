@@ -6,15 +6,12 @@
 // device idle. polar_hip_decode_set (per-SNR frozen sets, mixed N = 2^10 .. 2^16 batches) sorts
 // its jobs in two: those that fill the device on their own (two sweeps and more of 128-frame groups) are
 // launched one after the other as polar_hip_decode would; all the others share ONE launch of a team kernel
-// ((64, 7) or (32, 8), see below), whose workgroups are dealt to the jobs so that all of them finish together: a job of
-// `units` teams that gets `blocks` workgroups takes ceil(units / blocks) walks of its program, a walk is
-// about N / 16 device operations of 2 us, and the smallest common finishing time for which the workgroups
-// add up to the resident ones is found by bisection. One launch on one queue: several launches on streams
-// of their own overlap only as far as the streams happen to sit on different hardware queues (four per
-// process here; profiles/r3_bench_E_streams.txt).
+// ((64, 7) or (32, 8), see below): their teams form one queue, the largest codes first, and every resident
+// workgroup takes the next team from it when it has finished one (decode_kernel.hpp), so the workgroups finish
+// together whatever the mix. One launch on one queue: several launches on streams of their own overlap only as
+// far as the streams happen to sit on different hardware queues (four per process here;
+// profiles/r3_bench_E_streams.txt).
 enum { SET_Q = 8, SET_RL = 8, SET_TEAM = 4 };
-
-static double set_walk_ms(int top) { return (double)((size_t)1 << top) * 1.25e-4; }
 
 extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jobs, int count)
 {
@@ -86,89 +83,61 @@ extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jo
 		size_t resident = (size_t)per_cu * h->cus;
 		if (h->cfg_max_waves && (size_t)h->cfg_max_waves / SET_TEAM < resident)
 			resident = (size_t)h->cfg_max_waves / SET_TEAM ? (size_t)h->cfg_max_waves / SET_TEAM : 1;
+		// the common queue: the jobs with the longest walks (largest codes) first, so that the last teams taken are short ones
+		std::sort(shared.begin(), shared.end(), [&](int x, int y) {
+			int tx = h->programs[jobs[x].program_id].host.top, ty = h->programs[jobs[y].program_id].host.top;
+			return tx != ty ? tx > ty : x < y;
+		});
 		const size_t m = shared.size();
-		std::vector<size_t> units(m), blocks(m);
-		std::vector<double> walk(m);
-		for (size_t k = 0; k < m; ++k) {
-			units[k] = jobs[shared[k]].frames / fpw;
-			walk[k] = set_walk_ms(h->programs[jobs[shared[k]].program_id].host.top);
-		}
-		// blocks for a common finishing time T: every job takes floor(T / walk) walks at most
-		auto need = [&](double T, std::vector<size_t> *out) {
-			size_t sum = 0;
-			for (size_t k = 0; k < m; ++k) {
-				size_t walks = (size_t)(T / walk[k]);
-				if (!walks)
-					return (size_t)-1;
-				size_t b = (units[k] + walks - 1) / walks;
-				if (out)
-					(*out)[k] = b;
-				sum += b;
-			}
-			return sum;
-		};
-		double lo = 0, hi = 0;
-		for (size_t k = 0; k < m; ++k) {
-			lo = walk[k] > lo ? walk[k] : lo;
-			hi += walk[k] * (double)units[k];
-		}
-		if (need(lo, nullptr) > resident) {
-			for (int it = 0; it < 60; ++it) {
-				double mid = 0.5 * (lo + hi);
-				(need(mid, nullptr) <= resident ? hi : lo) = mid;
-			}
-			lo = hi;
-		}
-		need(lo, &blocks);
-		// what is left over goes to the jobs with the most walks per workgroup
-		size_t used = 0;
-		for (size_t b : blocks)
-			used += b;
-		// arenas and the argument table
 		std::vector<DecodeArgs> table(m + 1);
-		size_t arena_dwords = 0, first = 0;
+		size_t first = 0, block_dwords = 0;
 		for (size_t k = 0; k < m; ++k) {
 			LoadedProgram &lp = h->programs[jobs[shared[k]].program_id];
 			if ((rc = upload_shape(lp, v)))
 				return rc;
-			const size_t soft = (size_t)set_q << lp.host.top, block_dwords = soft + 2 * (soft / 8);
+			const size_t soft = (size_t)set_q << lp.host.top;
+			if (soft + 2 * (soft / 8) > block_dwords)
+				block_dwords = soft + 2 * (soft / 8); // every workgroup's arenas hold the largest code of the set
 			DecodeArgs &t = table[k];
 			t = DecodeArgs{};
 			t.prog = lp.dev[program_shape(v)];
 			t.cw = (const uint8_t *)jobs[shared[k]].codeword;
 			t.msg = (uint8_t *)jobs[shared[k]].message;
-			t.block_dwords = block_dwords;
 			t.stride = jobs[shared[k]].frames;
-			t.groups = (u32)(units[k] * SET_TEAM);
 			t.top = lp.host.top;
-			t.hot_top = set_rl;
 			t.set_first = (u32)first;
-			t.scratch = (u32 *)(uintptr_t)arena_dwords; // offset for now: the base is known after the reserve
-			arena_dwords += blocks[k] * SET_TEAM * block_dwords;
-			first += blocks[k];
+			first += jobs[shared[k]].frames / fpw;
 		}
 		table[m] = DecodeArgs{};
 		table[m].set_first = (u32)first;
+		if (first > 0x7FFFFFFFu)
+			return fail(POLAR_E_ARG, "polar_hip_decode_set: too many frames for one call");
+		const size_t grid = first < resident ? first : resident;
+		const size_t table_bytes = (table.size() * sizeof(DecodeArgs) + 255) / 256 * 256;
 		HIP_TRY(hipStreamSynchronize(h->stream)); // the jobs launched above may still use the arenas that the reserve replaces
-		if ((rc = h->scratch.reserve_arenas(arena_dwords * sizeof(u32), h->device)) || (rc = h->set_table.reserve(table.size() * sizeof(DecodeArgs))))
+		if ((rc = h->scratch.reserve_arenas(grid * SET_TEAM * block_dwords * sizeof(u32), h->device)) || (rc = h->set_table.reserve(table_bytes + 256)))
 			return rc;
-		for (size_t k = 0; k < m; ++k)
-			table[k].scratch = (u32 *)h->scratch.p + (size_t)(uintptr_t)table[k].scratch;
+		u32 *counter = (u32 *)((char *)h->set_table.p + table_bytes);
 		HIP_TRY(hipMemcpyAsync(h->set_table.p, table.data(), table.size() * sizeof(DecodeArgs), hipMemcpyHostToDevice, h->stream));
+		HIP_TRY(hipMemsetAsync(counter, 0, sizeof(u32), h->stream));
 		HIP_TRY(hipStreamSynchronize(h->stream)); // the table is a local
 		if (getenv("POLAR_HIP_DEBUG"))
-			fprintf(stderr, "polar_hip: decode set: %zu of %d jobs share one launch of %zu workgroups (%zu resident), common time %.2f ms by the model\n", m, count, first, resident, lo);
+			fprintf(stderr, "polar_hip: decode set: %zu of %d jobs share one launch: %zu teams for %zu workgroups (Q=%d)\n", m, count, first, grid, set_q);
 		DecodeArgs a = {};
 		a.set = (const DecodeArgs *)h->set_table.p;
 		a.set_jobs = (u32)m;
+		a.set_counter = counter;
+		a.scratch = (u32 *)h->scratch.p;
+		a.block_dwords = block_dwords;
+		a.top = table[0].top;
+		a.hot_top = set_rl;
 		h->placement.pending = false;
 		h->timed = false;
 		h->last_shape[0] = 4 * v->q;
 		h->last_shape[1] = v->rl;
 		h->last_shape[2] = v->team;
-		hipLaunchKernelGGL(v->fn, dim3((unsigned)first), dim3(64 * (unsigned)v->team), 0, h->stream, a);
+		hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(64 * (unsigned)v->team), 0, h->stream, a);
 		HIP_TRY(hipGetLastError());
-		(void)used;
 	}
 	HIP_TRY(hipStreamSynchronize(h->stream));
 	return POLAR_OK;

@@ -23,9 +23,11 @@ struct DecodeArgs {
 	size_t hot_dwords;     // (Q << (hot_top + 1)) - (Q << (RL + 1)), 0 when there is no hot level
 	unsigned long long *prof; // diagnostic build (POLAR_PROFILE) only
 	// a set of jobs in one launch (team kernels, polar_hip_decode_set): `set` = set_jobs + 1 entries of this
-	// struct in device memory, entry j = the arguments of job j and set_first = its first workgroup; the last
-	// entry only carries the total. 0 jobs: an ordinary launch.
+	// struct in device memory, entry j = the arguments of job j and set_first = the position of its first team in
+	// the common queue; the last entry only carries the total; set_counter = the queue's head (zero at launch).
+	// 0 jobs: an ordinary launch.
 	const DecodeArgs *set;
+	u32 *set_counter;
 	u32 set_jobs;
 	u32 set_first;
 };
@@ -78,51 +80,60 @@ __global__ void __launch_bounds__(64 * TEAM_WAVES, 2) sc_decode_team_kernel(Deco
 {
 	typedef Group<Q, RL, true> G;
 	__shared__ __attribute__((aligned(16))) u32 lds[TEAM_WAVES * G::LDS_DWORDS];
-	u32 nb = gridDim.x, b = blockIdx.x;
-	const u32 w = threadIdx.x >> 6;
-	if (a.set_jobs) {
-		// One launch, several jobs (codes, batch sizes): this workgroup is workgroup b - first of the
-		// next - first that job j was given, and runs on job j's arguments (scalar loads, like the program).
-		typedef const __attribute__((address_space(4))) DecodeArgs *table_ptr;
-		const table_ptr tab = (table_ptr)a.set;
-		u32 j = 0;
-		for (u32 k = 1; k < a.set_jobs; ++k)
-			j += b >= tab[k].set_first;
-		const u32 first = tab[j].set_first;
-		nb = tab[j + 1].set_first - first;
-		b -= first;
-		a.prog = tab[j].prog;
-		a.cw = tab[j].cw;
-		a.msg = tab[j].msg;
-		a.scratch = tab[j].scratch;
-		a.block_dwords = tab[j].block_dwords;
-		a.stride = tab[j].stride;
-		a.groups = tab[j].groups;
-		a.top = tab[j].top;
-		a.hot_top = RL;
-		a.hot = nullptr;
-		a.hot_dwords = 0;
-	}
+	const u32 nb = gridDim.x, b = blockIdx.x, w = threadIdx.x >> 6;
 	const u32 slot = (nb % 8 == 0) ? (b % 8) * (nb / 8) + b / 8 : b;
 	u32 *arena = a.scratch ? a.scratch + ((size_t)b * TEAM_WAVES + w) * a.block_dwords : nullptr;
-	const size_t plane = ((size_t)Q << a.top) / 8;
 	G g;
 	g.sl = (lds_u32 *)lds + w * G::LDS_DWORDS;
 	g.hls = g.sl + G::LDS_SOFT;
 	g.hlz = g.hls + G::LDS_PLANE;
 	g.sg = arena;
 	g.hgs = arena ? arena + ((size_t)Q << a.top) : nullptr;
-	g.hgz = arena ? g.hgs + plane : nullptr;
+	g.hgz = arena ? g.hgs + ((size_t)Q << a.top) / 8 : nullptr;
 	g.top = a.top;
 	g.hot_top = a.hot_top;
 	g.sh = a.hot ? a.hot + ((size_t)b * TEAM_WAVES + w) * a.hot_dwords - ((size_t)Q << (RL + 1)) : nullptr;
 #ifdef POLAR_PROFILE
 	g.prof = a.prof;
 #endif
-	for (u32 base = 0; base < a.groups; base += TEAM_WAVES * nb) {
-		u32 grp = base + TEAM_WAVES * slot + w;
-		if (base + TEAM_WAVES * slot >= a.groups) // whole teams only (a.groups is a multiple of TEAM_WAVES)
-			continue;
+	// One launch, several jobs (polar_hip_decode_set): the teams of all jobs form one queue, longest walks first,
+	// and every workgroup takes the next team from it when it has finished one (a counter in device memory,
+	// handed to the four wavefronts through the first LDS word, which is dead between two walks); a workgroup
+	// leaves when the queue is empty. Job j's arguments come from a table (scalar loads, like the program);
+	// all jobs use this workgroup's arenas, sized for the largest code of the set.
+	typedef const __attribute__((address_space(4))) DecodeArgs *table_ptr;
+	const table_ptr tab = (table_ptr)a.set;
+	const u32 jobs = a.set_jobs;
+	for (u32 base = 0;; base += TEAM_WAVES * nb) {
+		u32 grp;
+		if (jobs) {
+			__syncthreads(); // every wavefront is done with the LDS of its last walk
+			if (threadIdx.x == 0)
+				lds[0] = atomicAdd(a.set_counter, 1u);
+			__syncthreads();
+			const u32 unit = (u32)__builtin_amdgcn_readfirstlane((int)lds[0]);
+			__syncthreads(); // ... and has read the word before the walk overwrites it
+			if (unit >= tab[jobs].set_first)
+				break;
+			u32 j = 0;
+			for (u32 k = 1; k < jobs; ++k)
+				j += unit >= tab[k].set_first;
+			a.prog = tab[j].prog;
+			a.cw = tab[j].cw;
+			a.msg = tab[j].msg;
+			a.stride = tab[j].stride;
+			a.top = tab[j].top;
+			g.top = a.top;
+			g.hgs = arena + ((size_t)Q << a.top);
+			g.hgz = g.hgs + ((size_t)Q << a.top) / 8;
+			grp = (unit - tab[j].set_first) * TEAM_WAVES + w;
+		} else {
+			if (base >= a.groups)
+				break;
+			if (base + TEAM_WAVES * slot >= a.groups) // whole teams only (a.groups is a multiple of TEAM_WAVES)
+				continue;
+			grp = base + TEAM_WAVES * slot + w;
+		}
 		size_t g0 = (size_t)grp * (4 * Q);
 		g.in = typename G::In{a.cw + g0, a.stride};
 		g.out = OutRows<Q>{a.msg + g0, a.stride};
