@@ -60,15 +60,34 @@ __global__ void __launch_bounds__(64, (Group<Q, RL>::PIPELINE ? 2 : 4)) sc_decod
 #ifdef POLAR_PROFILE
 	g.prof = a.prof;
 #endif
+#if defined(POLAR_PROFILE) || defined(POLAR_SPAN)
+	const unsigned long long t_start_ = __builtin_amdgcn_s_memtime();
+#endif
 	for (u32 base = 0; base < a.groups; base += nb) {
 		u32 grp = base + slot;
 		if (grp >= a.groups)
 			continue;
+#ifdef POLAR_PRIO_ALTERNATE
+		// the SIMD favours the older of its two wavefronts (those of the first half of the grid): in every other
+		// walk the younger one asks for the higher priority instead
+		if (b >= nb / 2) {
+			if ((base / nb) & 1)
+				__builtin_amdgcn_s_setprio(1);
+			else
+				__builtin_amdgcn_s_setprio(0);
+		}
+#endif
 		size_t g0 = (size_t)grp * (4 * Q);
 		g.in = typename G::In{a.cw + g0, a.stride};
 		g.out = OutRows<Q>{a.msg + g0, a.stride};
 		g.run((prog_ptr)a.prog);
 	}
+#if defined(POLAR_PROFILE) || defined(POLAR_SPAN)
+	if (a.prof && threadIdx.x == 0 && b < 4096) { // diagnostic: when this wavefront started and ended (constant-rate counter)
+		a.prof[1024 + 2 * b] = t_start_;
+		a.prof[1024 + 2 * b + 1] = __builtin_amdgcn_s_memtime();
+	}
+#endif
 }
 
 // Team form: a workgroup of TEAM_WAVES wavefronts, wavefront w of block b takes the groups

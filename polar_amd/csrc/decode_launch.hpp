@@ -189,18 +189,18 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 		}
 	}
 	a.prof = nullptr;
-#ifdef POLAR_PROFILE
+#if defined(POLAR_PROFILE) || defined(POLAR_SPAN)
 	static unsigned long long *prof_dev = nullptr;
 	if (!prof_dev)
-		HIP_TRY(hipMalloc((void **)&prof_dev, 16 * 32 * 2 * 8));
-	HIP_TRY(hipMemsetAsync(prof_dev, 0, 16 * 32 * 2 * 8, stream));
+		HIP_TRY(hipMalloc((void **)&prof_dev, (16 * 32 * 2 + 2 * 4096) * 8));
+	HIP_TRY(hipMemsetAsync(prof_dev, 0, (16 * 32 * 2 + 2 * 4096) * 8, stream));
 	a.prof = prof_dev;
 #endif
 	if (timed)
 		HIP_TRY(hipEventRecord(h->ev0, stream));
 	hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64 * (unsigned)team), 0, stream, a);
 	HIP_TRY(hipGetLastError());
-#ifdef POLAR_PROFILE
+#if defined(POLAR_PROFILE) || defined(POLAR_SPAN)
 	{
 		static unsigned long long host[16 * 32 * 2];
 		HIP_TRY(hipMemcpyAsync(host, prof_dev, sizeof(host), hipMemcpyDeviceToHost, stream));
@@ -209,6 +209,47 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 		unsigned long long total = 0;
 		for (int i = 0; i < 16 * 32; ++i)
 			total += host[2 * i];
+		{
+			static unsigned long long span[2 * 4096];
+			HIP_TRY(hipMemcpy(span, prof_dev + 16 * 32 * 2, sizeof(span), hipMemcpyDeviceToHost));
+			// the counter is per XCD (different offsets): lifetimes, not absolute times; all wavefronts of a launch
+			// that fits the device start within microseconds of one another
+			std::vector<double> life;
+			for (size_t i = 0; i < blocks && i < 4096; ++i)
+				if (span[2 * i])
+					life.push_back((double)(span[2 * i + 1] - span[2 * i]));
+			{
+				double by8[8] = {}, n8[8] = {};
+				for (size_t i = 0; i < blocks && i < 4096; ++i)
+					if (span[2 * i]) {
+						by8[i % 8] += (double)(span[2 * i + 1] - span[2 * i]);
+						n8[i % 8] += 1;
+					}
+				fprintf(stderr, "polar_hip profile: mean lifetime by workgroup index mod 8 (XCD under round-robin dispatch):");
+				for (int k = 0; k < 8; ++k)
+					fprintf(stderr, " %.0f", n8[k] ? by8[k] / n8[k] : 0.0);
+				fprintf(stderr, "\npolar_hip profile: mean lifetime by workgroup index / 64 (arena address order):");
+				for (size_t k = 0; k * 64 < blocks && k < 64; ++k) {
+					double sum = 0, n = 0;
+					for (size_t i = k * 64; i < (k + 1) * 64 && i < blocks; ++i)
+						if (span[2 * i]) {
+							sum += (double)(span[2 * i + 1] - span[2 * i]);
+							n += 1;
+						}
+					fprintf(stderr, " %.0f", n ? sum / n / 1e6 : 0.0);
+				}
+				fprintf(stderr, "\n");
+			}
+			if (!life.empty()) {
+				std::sort(life.begin(), life.end());
+				double sum = 0;
+				for (double e : life)
+					sum += e;
+				auto q = [&](double f) { return life[(size_t)(f * (life.size() - 1))]; };
+				fprintf(stderr, "polar_hip profile: wavefront lifetimes (ticks of s_memtime), %zu wavefronts: min %.0f  5%% %.0f  25%% %.0f  median %.0f  75%% %.0f  95%% %.0f  max %.0f  mean %.0f (%.1f %% of max)\n",
+					life.size(), life.front(), q(0.05), q(0.25), q(0.5), q(0.75), q(0.95), life.back(), sum / life.size(), 100.0 * sum / life.size() / life.back());
+			}
+		}
 		fprintf(stderr, "polar_hip profile: wave-cycles per node kind and level (blocks=%zu, total %.3e cycles = %.1f Mcycles per wave)\n", blocks, (double)total, total / 1e6 / blocks);
 		for (int k = 0; k < 16; ++k)
 			for (int l = 0; l < 32; ++l)
