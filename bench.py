@@ -482,6 +482,13 @@ def main():
                 "kernel": ("sc_decode_team_kernel<%d, %d, %d>" % (shape[0] // 4, shape[1], shape[2])) if shape[2] > 1 else "sc_decode_kernel<%d, %d>" % (shape[0] // 4, shape[1]),
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": alg}
+        launches = sess.last_decode_launches()
+        if launches > 1:
+            # one decode of the batch = `launches` relay launches of whole sweeps on two streams (decode_launch.hpp);
+            # they overlap, so the unit of this block is the decode: kernel_ms runs from the start of the first
+            # launch to the end of the last (HIP events on the launch stream, around the fork and the join)
+            roof["launches_per_decode"] = launches
+            roof["note"] = "launch = one decode of the batch, sent as %d overlapping relay launches; kernel_ms = first start to last end" % launches
         if prof:
             # counters of the same command under rocprofv3 (profiles/): real HBM bytes per launch
             # over the live kernel time, and the VALU / LDS figures north_star asks for

@@ -275,7 +275,16 @@ int polar_hip_synchronize(polar_hip_handle *h);
  * used: frames per wavefront, highest LLR level in LDS, team size (each pointer may be NULL). */
 int polar_hip_last_decode_shape(polar_hip_handle *h, int *frames_per_wave, int *lds_level, int *team);
 
-/* Milliseconds the GPU spent in the decode kernel of the last polar_hip_decode call, or of the
+/* Kernel launches of the last decode on this handle: 1, or the number of relay launches a batch of several
+ * sweeps went out as (whole sweeps each, alternately on the call's stream and on a second stream forked from
+ * and joined to it, with a second set of arenas; the older wavefront of a SIMD finishes 11 % before the
+ * younger one, and the next launch moves into the places it leaves). Same results either way;
+ * POLAR_HIP_RELAY=1 in the environment turns it off. No counterpart in the reference (testbench.cc:170-175
+ * is one loop). */
+int polar_hip_last_decode_launches(polar_hip_handle *h);
+
+/* Milliseconds the GPU spent in the decode kernel of the last polar_hip_decode call (first launch's start to
+ * last launch's end when there were several), or of the
  * last chunk of the last polar_hip_simulate call (HIP events on the launch stream; the region
  * testbench.cc:170-175 times), or a negative error. */
 float polar_hip_last_decode_ms(polar_hip_handle *h);

@@ -253,6 +253,12 @@ class Session:
         _check(lib.polar_hip_last_decode_shape(self._h, ctypes.byref(f), ctypes.byref(r), ctypes.byref(t)), "polar_hip_last_decode_shape")
         return f.value, r.value, t.value
 
+    def last_decode_launches(self):
+        """Kernel launches the last decode went out as (relay launches of whole sweeps; 1 = a single launch)."""
+        n = lib.polar_hip_last_decode_launches(self._h)
+        _check(min(n, 0), "polar_hip_last_decode_launches")
+        return n
+
     def last_decode_ms(self):
         ms = lib.polar_hip_last_decode_ms(self._h)
         if ms < 0:

@@ -126,6 +126,13 @@ extern "C" int polar_hip_last_decode_shape(polar_hip_handle *h, int *frames_per_
 	return POLAR_OK;
 }
 
+extern "C" int polar_hip_last_decode_launches(polar_hip_handle *h)
+{
+	if (!h || !h->last_shape[0])
+		return fail(POLAR_E_ARG, "polar_hip_last_decode_launches: no decode on this handle");
+	return h->last_launches;
+}
+
 extern "C" float polar_hip_last_decode_ms(polar_hip_handle *h)
 {
 	if (!h || !h->timed)

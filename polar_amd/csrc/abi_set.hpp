@@ -136,6 +136,7 @@ extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jo
 		h->last_shape[0] = 4 * v->q;
 		h->last_shape[1] = v->rl;
 		h->last_shape[2] = v->team;
+		h->last_launches = 1;
 		hipLaunchKernelGGL(v->fn, dim3((unsigned)grid), dim3(64 * (unsigned)v->team), 0, h->stream, a);
 		HIP_TRY(hipGetLastError());
 	}

@@ -10,7 +10,7 @@
 // the two stays, the other is freed; PLACEMENT_CANDIDATES new placements are looked at this way, one call
 // each, the best one is kept. Results do not depend on it. Arenas of 1 GiB and more, and only while a
 // second copy fits the free device memory; POLAR_HIP_PLACEMENT=0 turns it off.
-enum { PLACEMENT_CANDIDATES = 3 };
+enum { PLACEMENT_CANDIDATES = 3, RELAY_PARTS = 4 };
 static void placement_step(polar_hip_handle *h, int program_id, size_t frames, const KernelVariant *v, size_t bytes)
 {
 	static const bool off = getenv("POLAR_HIP_PLACEMENT") && atoi(getenv("POLAR_HIP_PLACEMENT")) == 0;
@@ -132,13 +132,39 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	blocks = (units + sweeps - 1) / sweeps;
 	if (blocks >= 8 && blocks % 8) // multiple of 8 for the XCD-aware group order
 		blocks = blocks + 8 - blocks % 8 <= max_blocks ? blocks + 8 - blocks % 8 : blocks - blocks % 8;
+	// Relay launches. The SIMD favours the older of its two wavefronts: in one launch of s sweeps the wavefronts
+	// of the first half of the grid finish 11 % before the others and their places stay empty for the rest of
+	// the kernel (profiles/r3_wave_lifetimes.txt). So a batch of several sweeps goes out as RELAY_PARTS launches
+	// of whole sweeps, alternately on the caller's stream and on a second one that is forked from it and joined
+	// to it again: the workgroups of launch p + 1 move into the places that those of launch p leave, and only
+	// the last launch has a tail. Two launches can be resident at once, so there are two sets of arenas, used
+	// alternately (launch p + 2 follows launch p on the same stream). Where the two streams share a hardware
+	// queue the launches run one after the other: the time of the single launch. Not with a configured share
+	// of the device (max_waves: the lanes of a caller who overlaps launches himself), not for ragged batches,
+	// and only while the second set of arenas fits. POLAR_HIP_RELAY=<parts> (0 or 1: off) overrides.
+	size_t parts = 1, part_sweeps = sweeps;
+#if !defined(POLAR_PROFILE) && !defined(POLAR_SPAN)
+	{
+		const int relay_env = getenv("POLAR_HIP_RELAY") ? atoi(getenv("POLAR_HIP_RELAY")) : -1;
+		size_t want = relay_env >= 0 ? (size_t)relay_env : (size_t)RELAY_PARTS;
+		if (want > 1 && direct && sweeps >= 2 && !h->cfg_max_waves && blocks >= (size_t)per_cu * h->cus / 2 &&
+			(!block_dwords || budget.fits(2 * blocks * team * block_dwords * sizeof(u32)))) {
+			part_sweeps = (sweeps + want - 1) / want;
+			parts = (sweeps + part_sweeps - 1) / part_sweeps;
+		}
+	}
+#endif
+	const size_t sets = parts > 1 ? 2 : 1;
 	if (getenv("POLAR_HIP_DEBUG"))
 		fprintf(stderr, "polar_hip: scratch %p (%zu MiB) hot %p (%zu MiB)\n", h->scratch.p, h->scratch.bytes >> 20, h->hot.p, h->hot.bytes >> 20);
 	if (getenv("POLAR_HIP_DEBUG"))
 		fprintf(stderr, "polar_hip: decode Q=%d RL=%d team=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d hot levels <= %d\n", v->q, v->rl, v->team, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct, hot_top_for(v, lp.host.top, blocks * team));
+	if (getenv("POLAR_HIP_DEBUG") && parts > 1)
+		fprintf(stderr, "polar_hip: %zu relay launches of %zu sweeps\n", parts, part_sweeps);
 	h->last_shape[0] = 4 * v->q;
 	h->last_shape[1] = v->rl;
 	h->last_shape[2] = v->team;
+	h->last_launches = (int)parts;
 	DecodeArgs a = {};
 	a.prog = lp.dev[shape];
 	a.cw = cw;
@@ -168,22 +194,22 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 				h->hot.release();
 		}
 		if (tune_placement && timed && direct && stream == h->stream)
-			placement_step(h, program_id, frames, v, blocks * team * block_dwords * sizeof(u32) + slack);
+			placement_step(h, program_id, frames, v, sets * blocks * team * block_dwords * sizeof(u32) + slack);
 		else
 			h->placement.pending = false;
 		// experiments: POLAR_HIP_ARENA_PIECES = "<MiB per piece>[s]": the arenas as separately allocated pieces of
 		// device memory mapped into one range, in a shuffled order with an 's', the range aligned to the piece size with an 'a'
 		if (const char *pe = getenv("POLAR_HIP_ARENA_PIECES")) {
-			if (atoi(pe) > 0 && !strchr(pe, 'd') && (rc = h->scratch.reserve_chunked(blocks * team * block_dwords * sizeof(u32) + slack, (size_t)atoi(pe) << 20, strchr(pe, 's') != nullptr, h->device, strchr(pe, 'a') != nullptr)))
+			if (atoi(pe) > 0 && !strchr(pe, 'd') && (rc = h->scratch.reserve_chunked(sets * blocks * team * block_dwords * sizeof(u32) + slack, (size_t)atoi(pe) << 20, strchr(pe, 's') != nullptr, h->device, strchr(pe, 'a') != nullptr)))
 				return rc;
 		}
-		if ((rc = h->scratch.reserve_arenas(blocks * team * block_dwords * sizeof(u32) + slack, h->device)))
+		if ((rc = h->scratch.reserve_arenas(sets * blocks * team * block_dwords * sizeof(u32) + slack, h->device)))
 			return rc;
 		a.scratch = (u32 *)((char *)h->scratch.p + skew);
 		a.hot_top = hot_top_for(v, lp.host.top, blocks * team);
 		if (a.hot_top > v->rl) { // the wavefronts' hot levels side by side in one compact region
 			a.hot_dwords = ((size_t)v->q << (a.hot_top + 1)) - ((size_t)v->q << (v->rl + 1));
-			if ((rc = h->hot.reserve(blocks * team * a.hot_dwords * sizeof(u32) + slack)))
+			if ((rc = h->hot.reserve(sets * blocks * team * a.hot_dwords * sizeof(u32) + slack)))
 				return rc;
 			a.hot = (u32 *)((char *)h->hot.p + hskew);
 		}
@@ -198,8 +224,39 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 #endif
 	if (timed)
 		HIP_TRY(hipEventRecord(h->ev0, stream));
-	hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64 * (unsigned)team), 0, stream, a);
-	HIP_TRY(hipGetLastError());
+	if (parts > 1) {
+		if (!h->relay) {
+			HIP_TRY(hipStreamCreateWithFlags(&h->relay, hipStreamNonBlocking));
+			HIP_TRY(hipEventCreateWithFlags(&h->relay_fork, hipEventDisableTiming));
+			HIP_TRY(hipEventCreateWithFlags(&h->relay_join, hipEventDisableTiming));
+		}
+		HIP_TRY(hipEventRecord(h->relay_fork, stream));
+		HIP_TRY(hipStreamWaitEvent(h->relay, h->relay_fork, 0));
+		const size_t part_units = part_sweeps * blocks;
+		for (size_t p = 0; p < parts; ++p) {
+			const size_t first = p * part_units;
+			if (first >= units)
+				break;
+			const size_t count = p + 1 == parts || units - first < part_units ? units - first : part_units; // the last one takes what is left
+			DecodeArgs ap = a;
+			ap.cw = a.cw + first * fpw;
+			ap.msg = a.msg + first * fpw;
+			ap.groups = (u32)(count * team);
+			if (p & 1) { // the second set of arenas
+				if (ap.scratch)
+					ap.scratch += blocks * team * block_dwords;
+				if (ap.hot)
+					ap.hot += blocks * team * a.hot_dwords;
+			}
+			hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64 * (unsigned)team), 0, (p & 1) ? h->relay : stream, ap);
+			HIP_TRY(hipGetLastError());
+		}
+		HIP_TRY(hipEventRecord(h->relay_join, h->relay));
+		HIP_TRY(hipStreamWaitEvent(stream, h->relay_join, 0));
+	} else {
+		hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64 * (unsigned)team), 0, stream, a);
+		HIP_TRY(hipGetLastError());
+	}
 #if defined(POLAR_PROFILE) || defined(POLAR_SPAN)
 	{
 		static unsigned long long host[16 * 32 * 2];

@@ -118,6 +118,7 @@ struct DeviceBuffer {
 	void release()
 	{
 		if (piece_bytes) {
+			(void)hipDeviceSynchronize(); // hipFree waits for the device by itself, unmapping does not
 			for (size_t i = 0; i < mapped; ++i)
 				(void)hipMemUnmap((char *)p + i * piece_bytes, piece_bytes);
 			for (auto hnd : pieces)
@@ -148,6 +149,9 @@ struct polar_hip_handle {
 	hipStream_t own_stream = nullptr; // created with the handle
 	hipStream_t stream = nullptr;     // where the synchronous entry points enqueue: own_stream or the caller's (polar_hip_set_stream)
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	// relay launches (decode_launch.hpp): the second stream and the events that fork it from and join it to the caller's
+	hipStream_t relay = nullptr;
+	hipEvent_t relay_fork = nullptr, relay_join = nullptr;
 	// host-buffer pipeline (polar_hip_decode with pinned POLAR_HOST buffers): copy-in and copy-out
 	// streams beside `stream`, and per staging slot the events "copied in", "decoded", "copied out"
 	hipStream_t pipe_in = nullptr, pipe_out = nullptr;
@@ -183,6 +187,7 @@ struct polar_hip_handle {
 	} placement;
 	DeviceBuffer set_table; // polar_hip_decode_set: the argument table of the common launch
 	int last_shape[3] = {0, 0, 0}; // frames per wavefront, LDS level, team of the last decode launch
+	int last_launches = 1;         // kernel launches it went out as (relay launches, decode_launch.hpp)
 };
 
 static int use_device(polar_hip_handle *h)
@@ -375,6 +380,12 @@ extern "C" void polar_hip_destroy(polar_hip_handle *h)
 	h->sim_dec.release();
 	(void)hipEventDestroy(h->ev0);
 	(void)hipEventDestroy(h->ev1);
+	if (h->relay)
+		(void)hipStreamDestroy(h->relay);
+	if (h->relay_fork)
+		(void)hipEventDestroy(h->relay_fork);
+	if (h->relay_join)
+		(void)hipEventDestroy(h->relay_join);
 	if (h->bounce_in)
 		(void)hipHostFree(h->bounce_in);
 	if (h->bounce_out)

@@ -832,3 +832,42 @@ def test_arena_placement_choice_keeps_results(oracle, golden, capfd, monkeypatch
     log = capfd.readouterr().err
     assert log.count("arena placement") >= 4 and "arena placement 1:" in log, log[-2000:]
     sess.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,frames", [(10, 512 * 2001), (12, 512 * 601)])
+def test_relay_launches_keep_results(oracle, monkeypatch, M, frames):
+    """decode_launch.hpp, relay launches: a batch of several sweeps goes out as up to four launches of whole
+    sweeps, alternately on the call's stream and on a second one, with two sets of arenas. The decisions must be
+    those of the single launch (POLAR_HIP_RELAY=1) bit for bit, for a batch whose last launch is a partial one,
+    on repeated calls (the second set of arenas keeps the last call's contents), and the oracle's on a sample
+    of frames from every launch."""
+    import polar_amd
+
+    N = 1 << M
+    fro = _code(oracle, M)
+    prog = oracle.compile(fro, M)
+    sess = polar_amd.Session(0)
+    dec = polar_amd.PolarDecoder(sess)
+    g = torch.Generator(device="cuda").manual_seed(M)
+    llr = torch.randint(-40, 90, (N, frames), dtype=torch.int8, device="cuda", generator=g)
+    one = torch.empty((N // 2, frames), dtype=torch.int8, device="cuda")
+    monkeypatch.setenv("POLAR_HIP_RELAY", "1")
+    dec(one, llr, prog)
+    assert sess.last_decode_launches() == 1
+    for parts in ("4", "2", "3"):
+        monkeypatch.setenv("POLAR_HIP_RELAY", parts)
+        for _ in range(2):
+            out = torch.full((N // 2, frames), 77, dtype=torch.int8, device="cuda")
+            dec(out, llr, prog)
+            assert 1 < sess.last_decode_launches() <= int(parts), (parts, sess.last_decode_launches(), sess.last_decode_shape())
+            assert bool((out == one).all())
+    monkeypatch.delenv("POLAR_HIP_RELAY")
+    out = torch.full((N // 2, frames), 77, dtype=torch.int8, device="cuda")
+    dec(out, llr, prog)
+    assert sess.last_decode_launches() > 1 and bool((out == one).all())
+    cols = np.unique(np.concatenate([np.arange(0, 64), np.linspace(0, frames - 1, 200).astype(np.int64), np.arange(frames - 64, frames)]))
+    sample = llr[:, torch.from_numpy(cols).cuda()].cpu().numpy()
+    want = oracle.decode(sample, prog)
+    assert np.array_equal(out[:, torch.from_numpy(cols).cuda()].cpu().numpy(), want)
+    sess.close()
