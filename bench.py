@@ -69,7 +69,7 @@ SETTLE_CALLS = 4  # untimed decode calls of the set-up in which the library sett
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="B")
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (0 = the config's default)")
@@ -82,6 +82,7 @@ def parse(argv=None):
     ap.add_argument("--init-timeout", type=float, default=180.0, help="seconds a rank waits in the process-group rendezvous")
     ap.add_argument("--streams", type=int, default=0, help="config E: 0 = the library's polar_hip_decode_set (four internal lanes); k > 0 = k handles / HIP streams managed here (1 = back to back; experiments)")
     ap.add_argument("--lane-waves", type=int, default=0, help="config E: resident wavefronts per handle (0 = an equal share of the device)")
+    ap.add_argument("--contiguous-llr", action="store_true", help="LLR rows exactly `frames` bytes apart instead of the row pitch the library suggests (polar_hip_row_pitch)")
     ap.add_argument("--force-dist", action="store_true", help="join the RCCL process group even as a world of one (rehearses the N > 1 path on a one-GPU box)")
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)  # test: this rank exits 3 at start
     return ap.parse_args(argv)
@@ -206,13 +207,15 @@ def make_code(polar_amd, M):
     return fro, prog[:n].copy()
 
 
-def generate(torch, polar_amd, sess, fro, M, systematic, frames, seed, first_frame, dev, snr_db=SNR_DB):
+def generate(torch, polar_amd, sess, fro, M, systematic, frames, seed, first_frame, dev, snr_db=SNR_DB, pitched=False):
     """Resident batch: llr [N][frames] int8 and the decoder-domain (u) truth [K][frames].
     Message bits and noise come from the library's counter-based source (polar_hip_random_message,
     polar_hip_channel): global frame g is the same whatever rank or chunk produces it."""
     N = 1 << M
     K = N // 2
-    llr = torch.empty((N, frames), dtype=torch.int8, device=dev)
+    # pitched: rows polar_hip_row_pitch(frames) bytes apart (a view of a wider allocation), the layout the library
+    # suggests for decoder input whose rows would otherwise be a multiple of 4 KiB apart
+    llr = polar_amd.pitched_empty(N, frames, dev) if pitched else torch.empty((N, frames), dtype=torch.int8, device=dev)
     u_true = torch.empty((K, frames), dtype=torch.int8, device=dev)
     enc = (polar_amd.PolarSysEnc if systematic else polar_amd.PolarEncoder)(M, sess)
     plain = polar_amd.PolarEncoder(M, sess)
@@ -405,7 +408,7 @@ def main():
     frames = args.frames or default_frames
     fro, prog = make_code(polar_amd, M)
     seed, first = 42, rank * frames
-    llr, u_true, chan = generate(torch, polar_amd, sess, fro, M, systematic, frames, seed, first, dev)
+    llr, u_true, chan = generate(torch, polar_amd, sess, fro, M, systematic, frames, seed, first, dev, pitched=not args.contiguous_llr)
     out = torch.empty((K, frames), dtype=torch.int8, device=dev)
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
     dec = polar_amd.PolarDecoder(sess)
@@ -514,6 +517,7 @@ def main():
                     args.config, M, K, "systematic" if systematic else "non-systematic", frames, SNR_DB, what, " + RCCL all-reduce of the counters" if world > 1 else ""),
                 "frames_per_gpu": frames, "parallelism": "frames sharded over %d GPU(s)" % world,
                 "frames_per_wave": shape[0], "lds_level": shape[1], "team": shape[2], "shape_chosen_by": "caller" if args.fpw else "library default", "setup_decode_calls": SETTLE_CALLS,
+                "llr_row_pitch_bytes": int(llr.stride(0)),
             },
             "roofline": roof,
             "frac_of_hbm_roofline_whole_job": value * 1e9 * 3 / (HBM_PEAK_GBS * 1e9 * world),

@@ -275,6 +275,17 @@ int polar_hip_synchronize(polar_hip_handle *h);
  * used: frames per wavefront, highest LLR level in LDS, team size (each pointer may be NULL). */
 int polar_hip_last_decode_shape(polar_hip_handle *h, int *frames_per_wave, int *lds_level, int *team);
 
+/* polar_hip_decode for device buffers whose rows are `*_pitch` bytes apart instead of `frames` (0 = contiguous):
+ * column ranges of wider tensors (a sub-batch without a copy), or rows padded on purpose. Row lengths that are
+ * multiples of 4 KiB put every row at the same place of the device memory's address interleaving:
+ * polar_hip_row_pitch(frames) is the pitch this library suggests for an input buffer it will decode
+ * (frames + 4352 for such lengths: -1.5 % decode time at N = 2^16 with 2^20 frames, else frames rounded up to 16).
+ * Pitches that are multiples of 16 are used in place, others staged. The reference has no such notion (one SIMD
+ * vector per row, polar_decoder.hh:415). */
+int polar_hip_decode_pitched(polar_hip_handle *h, int program_id, int8_t *message, size_t message_pitch,
+                             const int8_t *codeword, size_t codeword_pitch, size_t frames);
+size_t polar_hip_row_pitch(size_t frames);
+
 /* Kernel launches of the last decode on this handle: 1, or the number of relay launches a batch of several
  * sweeps went out as (whole sweeps each, alternately on the call's stream and on a second stream forked from
  * and joined to it, with a second set of arenas; the older wavefront of a SIMD finishes 11 % before the

@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     PolarFreezer,
     PolarSysEnc,
     Session,
+    pitched_empty,
     testbench_probability,
 )
 from ._lib import LIB_PATH, lib  # noqa: F401

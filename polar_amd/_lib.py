@@ -24,6 +24,8 @@ SYMBOLS = {
     "polar_hip_configure": ([_vp, _i, _i, _i], _i),
     "polar_hip_configure_team": ([_vp, _i, _i, _i, _i], _i),
     "polar_hip_last_decode_launches": ([_vp], _i),
+    "polar_hip_decode_pitched": ([_vp, _i, _vp, _sz, _vp, _sz, _sz], _i),
+    "polar_hip_row_pitch": ([_sz], _sz),
     "polar_hip_last_decode_shape": ([_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i)], _i),
     "polar_hip_set_stream": ([_vp, _vp, _i], _i),
     "polar_hip_load_program": ([_vp, _vp, _i], _i),

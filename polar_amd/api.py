@@ -42,6 +42,25 @@ def _ptr(a):
     raise TypeError("expected a numpy array or a torch tensor")
 
 
+def _pitched(a):
+    """Row pitch in bytes of a 2-D int8 device tensor whose rows are contiguous but further apart than their
+    length (a column range of a wider tensor, pitched_empty), or None."""
+    if a is None or isinstance(a, np.ndarray) or not hasattr(a, "stride") or not a.is_cuda or a.dim() != 2 or a.is_contiguous():
+        return None
+    if a.element_size() != 1 or a.stride(1) != 1 or a.stride(0) < a.shape[1]:
+        return None
+    return int(a.stride(0))
+
+
+def pitched_empty(rows, frames, device="cuda"):
+    """int8 [rows][frames] device tensor with the row pitch the library suggests for decoder input
+    (polar_hip_row_pitch): a view of a [rows][pitch] allocation."""
+    import torch
+
+    pitch = int(lib.polar_hip_row_pitch(int(frames)))
+    return torch.empty((rows, pitch), dtype=torch.int8, device=device)[:, :frames]
+
+
 def _where(*ws):
     ws = [w for w in ws if w is not None]
     if any(w != ws[0] for w in ws):
@@ -299,6 +318,15 @@ class PolarDecoder:
         if codeword.shape[0] != n or (rows and (message.shape[0] < rows or _frames(message) != frames)):
             raise ValueError("buffer shapes do not match the program: codeword [%d][F], message [>=%d][F]" % (n, rows))
         self.session._order(codeword)
+        cpitch, mpitch = _pitched(codeword), _pitched(message)
+        if cpitch or mpitch:  # rows further apart than their length: device tensors, used in place
+            if not (getattr(codeword, "is_cuda", False) and getattr(message, "is_cuda", False)):
+                raise ValueError("pitched buffers must both be device tensors")
+            if (not cpitch and not codeword.is_contiguous()) or (not mpitch and not message.is_contiguous()):
+                raise ValueError("buffers must be [elements][frames] with contiguous rows")
+            _check(lib.polar_hip_decode_pitched(self.session._h, pid, ctypes.c_void_p(message.data_ptr()), mpitch or 0,
+                                                ctypes.c_void_p(codeword.data_ptr()), cpitch or 0, frames), "PolarDecoder(pitched)")
+            return
         mp, mw = _ptr(message)
         cp, cw = _ptr(codeword)
         if _is_f32(codeword) or _is_f32(message):  # TYPE = float lanes (testbench.cc:49-53): the reference's float helper

@@ -104,6 +104,7 @@ extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jo
 			t.cw = (const uint8_t *)jobs[shared[k]].codeword;
 			t.msg = (uint8_t *)jobs[shared[k]].message;
 			t.stride = jobs[shared[k]].frames;
+			t.msg_stride = t.stride;
 			t.top = lp.host.top;
 			t.set_first = (u32)first;
 			first += jobs[shared[k]].frames / fpw;

@@ -15,7 +15,8 @@ struct DecodeArgs {
 	uint8_t *msg;
 	u32 *scratch;          // per-block arenas, block_dwords each
 	size_t block_dwords;
-	size_t stride;         // bytes per row of cw and msg: a multiple of 4, groups * 4Q <= stride
+	size_t stride;         // bytes per row of cw: a multiple of 16, groups * 4Q <= stride
+	size_t msg_stride;     // bytes per row of msg, likewise
 	u32 groups;
 	int top;
 	int hot_top;           // scratch levels up to this one keep the default cache policy (sc_core.hpp, GVec::hot) ...
@@ -79,7 +80,7 @@ __global__ void __launch_bounds__(64, (Group<Q, RL>::PIPELINE ? 2 : 4)) sc_decod
 #endif
 		size_t g0 = (size_t)grp * (4 * Q);
 		g.in = typename G::In{a.cw + g0, a.stride};
-		g.out = OutRows<Q>{a.msg + g0, a.stride};
+		g.out = OutRows<Q>{a.msg + g0, a.msg_stride};
 		g.run((prog_ptr)a.prog);
 	}
 #if defined(POLAR_PROFILE) || defined(POLAR_SPAN)
@@ -141,6 +142,7 @@ __global__ void __launch_bounds__(64 * TEAM_WAVES, 2) sc_decode_team_kernel(Deco
 			a.cw = tab[j].cw;
 			a.msg = tab[j].msg;
 			a.stride = tab[j].stride;
+			a.msg_stride = tab[j].msg_stride;
 			a.top = tab[j].top;
 			g.top = a.top;
 			g.hgs = arena + ((size_t)Q << a.top);
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(64 * TEAM_WAVES, 2) sc_decode_team_kernel(Deco
 		}
 		size_t g0 = (size_t)grp * (4 * Q);
 		g.in = typename G::In{a.cw + g0, a.stride};
-		g.out = OutRows<Q>{a.msg + g0, a.stride};
+		g.out = OutRows<Q>{a.msg + g0, a.msg_stride};
 		g.run((prog_ptr)a.prog);
 	}
 }

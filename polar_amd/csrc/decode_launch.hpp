@@ -69,8 +69,13 @@ static void placement_step(polar_hip_handle *h, int program_id, size_t frames, c
 // Enqueues the decode of `frames` frames on `stream`. The kernel wants whole groups of 4Q frames
 // and dword-aligned rows; anything else is staged through padded device copies (zero-filled
 // tail frames decode to garbage that is never copied back).
-static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, hipStream_t stream, bool timed, bool tune_placement = false)
+// cw_pitch / msg_pitch: bytes from one row of the caller's buffer to the next (0: the rows are contiguous, `frames` apart).
+static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, const int8_t *codeword, size_t frames, hipStream_t stream, bool timed, bool tune_placement = false, size_t cw_pitch = 0, size_t msg_pitch = 0)
 {
+	if (!cw_pitch)
+		cw_pitch = frames;
+	if (!msg_pitch)
+		msg_pitch = frames;
 	LoadedProgram &lp = h->programs[program_id];
 	ScratchBudget budget{h};
 	const KernelVariant *v = pick_variant(h, lp.host.top, frames, budget);
@@ -89,14 +94,14 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	if (!groups)
 		return POLAR_OK;
 	const size_t padded = units * fpw;
-	const bool direct = padded == frames && (uintptr_t)codeword % 16 == 0 && (uintptr_t)message % 16 == 0;
+	const bool direct = padded == frames && (uintptr_t)codeword % 16 == 0 && (uintptr_t)message % 16 == 0 && cw_pitch % 16 == 0 && msg_pitch % 16 == 0;
 	const uint8_t *cw = (const uint8_t *)codeword;
 	uint8_t *msg = (uint8_t *)message;
 	if (!direct) {
 		if ((rc = h->pad_in.reserve(n * padded)) || (rc = h->pad_out.reserve((rows ? rows : 1) * padded)))
 			return rc;
 		HIP_TRY(hipMemsetAsync(h->pad_in.p, 0, n * padded, stream));
-		HIP_TRY(hipMemcpy2DAsync(h->pad_in.p, padded, codeword, frames, frames, n, hipMemcpyDeviceToDevice, stream));
+		HIP_TRY(hipMemcpy2DAsync(h->pad_in.p, padded, codeword, cw_pitch, frames, n, hipMemcpyDeviceToDevice, stream));
 		cw = (const uint8_t *)h->pad_in.p;
 		msg = (uint8_t *)h->pad_out.p;
 	}
@@ -169,10 +174,17 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	a.prog = lp.dev[shape];
 	a.cw = cw;
 	a.msg = msg;
-	a.stride = padded;
-	if (const char *e = getenv("POLAR_HIP_ROW_STRIDE")) // experiments: the caller's rows are this many bytes apart (a multiple of 16)
-		if (direct && (size_t)atol(e) >= padded && atol(e) % 16 == 0)
-			a.stride = (size_t)atol(e);
+	a.stride = direct ? cw_pitch : padded;
+	a.msg_stride = direct ? msg_pitch : padded;
+	// experiments: the caller's rows are this many bytes apart (a multiple of 16); _IN / _OUT: one side only
+	for (int side = 0; side < 3; ++side)
+		if (const char *e = getenv(side == 0 ? "POLAR_HIP_ROW_STRIDE" : side == 1 ? "POLAR_HIP_ROW_STRIDE_IN" : "POLAR_HIP_ROW_STRIDE_OUT"))
+			if (direct && cw_pitch == frames && msg_pitch == frames && (size_t)atol(e) >= padded && atol(e) % 16 == 0) {
+				if (side != 2)
+					a.stride = (size_t)atol(e);
+				if (side != 1)
+					a.msg_stride = (size_t)atol(e);
+			}
 	a.groups = (u32)groups;
 	a.top = lp.host.top;
 	a.hot_top = v->rl;
@@ -322,7 +334,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 			h->placement.pending = true;
 	}
 	if (!direct && rows)
-		HIP_TRY(hipMemcpy2DAsync(message, frames, msg, padded, frames, rows, hipMemcpyDeviceToDevice, stream));
+		HIP_TRY(hipMemcpy2DAsync(message, msg_pitch, msg, padded, frames, rows, hipMemcpyDeviceToDevice, stream));
 	return POLAR_OK;
 }
 

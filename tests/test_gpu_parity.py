@@ -871,3 +871,40 @@ def test_relay_launches_keep_results(oracle, monkeypatch, M, frames):
     want = oracle.decode(sample, prog)
     assert np.array_equal(out[:, torch.from_numpy(cols).cuda()].cpu().numpy(), want)
     sess.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,frames,pitches", [(8, 512, (512 + 4352, 1024)), (11, 1024, (1040, 1024 + 16)), (9, 200, (333, 208)), (12, 4096, (0, 8192))])
+def test_pitched_rows(oracle, M, frames, pitches):
+    """polar_hip_decode_pitched: rows of the caller's buffers further apart than their length (column ranges of
+    wider tensors; rows padded to polar_hip_row_pitch). Pitches that are multiples of 16 are used in place, others
+    and ragged batches staged; the decisions are the oracle's either way and nothing outside the rows is written."""
+    import polar_amd
+
+    N = 1 << M
+    fro = _code(oracle, M)
+    prog = oracle.compile(fro, M)
+    rows = int(N - fro.sum())
+    cpitch, mpitch = pitches
+    rng = np.random.default_rng(M * 1000 + frames)
+    llr = rng.integers(-60, 100, (N, frames), dtype=np.int8)
+    want = oracle.decode(llr, prog)
+    sess = polar_amd.Session(0)
+    dec = polar_amd.PolarDecoder(sess)
+    wide_in = torch.full((N, cpitch or frames), 99, dtype=torch.int8, device="cuda")
+    cw = wide_in[:, :frames]
+    cw.copy_(torch.from_numpy(llr))
+    wide_out = torch.full((rows, mpitch or frames), 55, dtype=torch.int8, device="cuda")
+    out = wide_out[:, :frames]
+    dec(out, cw, prog)
+    assert np.array_equal(out.cpu().numpy(), want)
+    if mpitch:
+        assert bool((wide_out[:, frames:] == 55).all())
+    # a sub-batch of a wider tensor, without a copy
+    a, b = (frames // 4) // 16 * 16, frames - 16
+    wide_out.fill_(55)
+    dec(wide_out[:, a:b], wide_in[:, a:b], prog)
+    assert np.array_equal(wide_out[:, a:b].cpu().numpy(), want[:, a:b])
+    assert bool((wide_out[:, :a] == 55).all()) and bool((wide_out[:, b:] == 55).all())
+    assert polar_amd.pitched_empty(4, 1 << 20).stride(0) == (1 << 20) + 4352 and polar_amd.pitched_empty(4, 100).stride(0) == 112
+    sess.close()

@@ -18,6 +18,7 @@ ap.add_argument("--frames", default="1048576")
 ap.add_argument("--pads", default="0", help="POLAR_HIP_ARENA_PAD values (dwords)")
 ap.add_argument("--hot", default="", help="POLAR_HIP_HOT_LEVELS values (needs a build that reads it per launch)")
 ap.add_argument("--strides", default="0", help="extra bytes per row (POLAR_HIP_ROW_STRIDE = frames + this), multiples of 16")
+ap.add_argument("--side", default="both", choices=["both", "in", "out"], help="which tensor gets the row stride")
 ap.add_argument("--skews", default="", help="POLAR_HIP_SCRATCH_SKEW values (bytes)")
 ap.add_argument("--hot-skews", default="", help="POLAR_HIP_HOT_SKEW values (bytes)")
 ap.add_argument("--rounds", type=int, default=3)
@@ -59,10 +60,11 @@ dec(out[: (N // 2) * f0].view(N // 2, f0), flat[: N * f0].view(N, f0), prog)
 for rnd in range(a.rounds):
     for f in frames:
       for extra in strides:
+        knob = {"both": "POLAR_HIP_ROW_STRIDE", "in": "POLAR_HIP_ROW_STRIDE_IN", "out": "POLAR_HIP_ROW_STRIDE_OUT"}[a.side]
         if extra:
-            os.environ["POLAR_HIP_ROW_STRIDE"] = str(f + extra)
+            os.environ[knob] = str(f + extra)
         else:
-            os.environ.pop("POLAR_HIP_ROW_STRIDE", None)
+            os.environ.pop(knob, None)
         for pad in pads:
           for sk in skews:
            for hsk in hskews:
