@@ -558,7 +558,7 @@ def run_config_e(torch, polar_amd, sess, args, rank, world, dev, dist):
     for j in jobs:
         # frames of different (N, SNR) batches never share a counter-based stream: the frame index space is split per job
         first = (jobs.index(j) * world + rank) * (1 << 24)
-        j["llr"], j["u"], st = generate(torch, polar_amd, sess, j["fro"], j["M"], 1, j["frames"], seed, first, dev, j["snr"])
+        j["llr"], j["u"], st = generate(torch, polar_amd, sess, j["fro"], j["M"], 1, j["frames"], seed, first, dev, j["snr"], pitched=not args.contiguous_llr and args.streams == 0)
         j["out"] = torch.empty(((1 << j["M"]) // 2, j["frames"]), dtype=torch.int8, device=dev)
         chan += st
     counters = torch.zeros(4, dtype=torch.int64, device=dev)

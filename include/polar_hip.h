@@ -154,6 +154,7 @@ typedef struct polar_hip_job {
 	int8_t *message;
 	const int8_t *codeword;
 	size_t frames;
+	size_t message_pitch, codeword_pitch; /* bytes from row to row, 0 = contiguous (polar_hip_decode_pitched) */
 } polar_hip_job;
 int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jobs, int count);
 

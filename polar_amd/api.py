@@ -341,7 +341,8 @@ class PolarDecoder:
         and batch sizes, decoded side by side on the handle's internal lanes; returns when all are done."""
 
         class Job(ctypes.Structure):
-            _fields_ = [("program_id", ctypes.c_int), ("message", ctypes.c_void_p), ("codeword", ctypes.c_void_p), ("frames", ctypes.c_size_t)]
+            _fields_ = [("program_id", ctypes.c_int), ("message", ctypes.c_void_p), ("codeword", ctypes.c_void_p), ("frames", ctypes.c_size_t),
+                        ("message_pitch", ctypes.c_size_t), ("codeword_pitch", ctypes.c_size_t)]
 
         arr = (Job * len(jobs))()
         for i, (message, codeword, program) in enumerate(jobs):
@@ -350,10 +351,12 @@ class PolarDecoder:
             frames = _frames(codeword)
             if codeword.shape[0] != n or (rows and (message.shape[0] < rows or _frames(message) != frames)):
                 raise ValueError("job %d: buffer shapes do not match the program" % i)
-            (mp, mw), (cp, cw) = _ptr(message), _ptr(codeword)
+            cpitch, mpitch = _pitched(codeword), _pitched(message)  # rows further apart than their length: used in place
+            (mp, mw) = (ctypes.c_void_p(message.data_ptr()), DEVICE) if mpitch else _ptr(message)
+            (cp, cw) = (ctypes.c_void_p(codeword.data_ptr()), DEVICE) if cpitch else _ptr(codeword)
             if _where(mw, cw) != DEVICE:
                 raise ValueError("job %d: the batches of a set are device tensors" % i)
-            arr[i] = Job(pid, mp.value, cp.value, frames)
+            arr[i] = Job(pid, mp.value, cp.value, frames, mpitch or 0, cpitch or 0)
         if jobs:
             self.session._order(jobs[0][1])
         _check(lib.polar_hip_decode_set(self.session._h, ctypes.cast(arr, ctypes.c_void_p), len(jobs)), "PolarDecoder.decode_set")

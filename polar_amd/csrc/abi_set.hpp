@@ -25,6 +25,8 @@ extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jo
 			return rc;
 		if (jobs[i].frames && (polar_hip_where(jobs[i].codeword) != POLAR_DEVICE || (h->programs[jobs[i].program_id].host.rows && polar_hip_where(jobs[i].message) != POLAR_DEVICE)))
 			return fail(POLAR_E_ARG, "polar_hip_decode_set: the batches of a set are device-resident (device pointers only)");
+		if ((jobs[i].codeword_pitch && jobs[i].codeword_pitch < jobs[i].frames) || (jobs[i].message_pitch && jobs[i].message_pitch < jobs[i].frames))
+			return fail(POLAR_E_ARG, "polar_hip_decode_set: a row pitch below the row length");
 	}
 	// the common launch: (64, 7) teams when the jobs that will share it bring at least one team per resident
 	// workgroup (8 % faster than (32, 8) teams under load: config E 118 -> 127 Gbit/s), else (32, 8) teams (more,
@@ -55,17 +57,17 @@ extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jo
 		if (!jobs[i].frames)
 			continue;
 		const LoadedProgram &lp = h->programs[jobs[i].program_id];
-		const bool direct = jobs[i].frames % fpw == 0 && (uintptr_t)jobs[i].codeword % 16 == 0 && (uintptr_t)jobs[i].message % 16 == 0;
+		const bool direct = jobs[i].frames % fpw == 0 && (uintptr_t)jobs[i].codeword % 16 == 0 && (uintptr_t)jobs[i].message % 16 == 0 && jobs[i].codeword_pitch % 16 == 0 && jobs[i].message_pitch % 16 == 0;
 		// a configured shape, or two sweeps and more of the widest one: the job is not short of frames
 		const bool fills = h->cfg_frames_per_wave || jobs[i].frames / 128 >= (size_t)16 * h->cus;
 		if (v && direct && !fills && lp.host.top > set_rl)
 			shared.push_back(i);
-		else if ((rc = launch_decode(h, jobs[i].program_id, jobs[i].message, jobs[i].codeword, jobs[i].frames, h->stream, false)))
+		else if ((rc = launch_decode(h, jobs[i].program_id, jobs[i].message, jobs[i].codeword, jobs[i].frames, h->stream, false, false, jobs[i].codeword_pitch, jobs[i].message_pitch)))
 			return rc;
 	}
 	if (shared.size() == 1) { // nothing to share a launch with
 		int i = shared[0];
-		if ((rc = launch_decode(h, jobs[i].program_id, jobs[i].message, jobs[i].codeword, jobs[i].frames, h->stream, false)))
+		if ((rc = launch_decode(h, jobs[i].program_id, jobs[i].message, jobs[i].codeword, jobs[i].frames, h->stream, false, false, jobs[i].codeword_pitch, jobs[i].message_pitch)))
 			return rc;
 		shared.clear();
 	}
@@ -103,8 +105,8 @@ extern "C" int polar_hip_decode_set(polar_hip_handle *h, const polar_hip_job *jo
 			t.prog = lp.dev[program_shape(v)];
 			t.cw = (const uint8_t *)jobs[shared[k]].codeword;
 			t.msg = (uint8_t *)jobs[shared[k]].message;
-			t.stride = jobs[shared[k]].frames;
-			t.msg_stride = t.stride;
+			t.stride = jobs[shared[k]].codeword_pitch ? jobs[shared[k]].codeword_pitch : jobs[shared[k]].frames;
+			t.msg_stride = jobs[shared[k]].message_pitch ? jobs[shared[k]].message_pitch : jobs[shared[k]].frames;
 			t.top = lp.host.top;
 			t.set_first = (u32)first;
 			first += jobs[shared[k]].frames / fpw;

@@ -729,6 +729,19 @@ def test_mixed_sizes_in_one_launch_set(session, oracle):
     exp0 = torch.from_numpy(oracle.decode(np.ascontiguousarray(llr0), prog0)).cuda()
     assert bool((big_out.view(512, -1, 32) == exp0.view(512, 1, 32)).all())
     del big_in, big_out
+    # the same shared launch with rows further apart than their length (polar_hip_job's pitches): input and output
+    # as column ranges of wider tensors; nothing outside the ranges is written
+    pitched = []
+    for k, (prog, llr, d_llr, _o) in enumerate(shared):
+        frames = llr.shape[1]
+        wide_in = torch.full((llr.shape[0], frames + 16 * (k + 1)), 77, dtype=torch.int8, device="cuda")
+        wide_in[:, 16:16 + frames] = d_llr
+        wide_out = torch.full((llr.shape[0] // 2, frames + 4352), 9, dtype=torch.int8, device="cuda")
+        pitched.append((prog, llr, wide_in, wide_out))
+    dec.decode_set([(wo[:, :llr.shape[1]], wi[:, 16:16 + llr.shape[1]], prog) for prog, llr, wi, wo in pitched])
+    for prog, llr, _wi, wo in pitched:
+        assert (wo[:, :llr.shape[1]].cpu().numpy() == oracle.decode(llr, prog)).all(), ("pitched shared launch", int(prog[0]))
+        assert bool((wo[:, llr.shape[1]:] == 9).all())
     with pytest.raises(ValueError):
         dec.decode_set([(np.zeros((512, 4), np.int8), np.zeros((1024, 4), np.int8), jobs[0][0])])  # host buffers are refused
 
