@@ -487,7 +487,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg}
         launches = sess.last_decode_launches()
         if launches > 1:
-            # one decode of the batch = `launches` relay launches of whole sweeps on two streams (decode_launch.hpp);
+            # one decode of the batch = `launches` relay launches of half a grid each on two streams (decode_launch.hpp);
             # they overlap, so the unit of this block is the decode: kernel_ms runs from the start of the first
             # launch to the end of the last (HIP events on the launch stream, around the fork and the join)
             roof["launches_per_decode"] = launches

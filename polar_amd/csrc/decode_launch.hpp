@@ -10,7 +10,7 @@
 // the two stays, the other is freed; PLACEMENT_CANDIDATES new placements are looked at this way, one call
 // each, the best one is kept. Results do not depend on it. Arenas of 1 GiB and more, and only while a
 // second copy fits the free device memory; POLAR_HIP_PLACEMENT=0 turns it off.
-enum { PLACEMENT_CANDIDATES = 3, RELAY_PARTS = 4 };
+enum { PLACEMENT_CANDIDATES = 3 };
 static void placement_step(polar_hip_handle *h, int program_id, size_t frames, const KernelVariant *v, size_t bytes)
 {
 	static const bool off = getenv("POLAR_HIP_PLACEMENT") && atoi(getenv("POLAR_HIP_PLACEMENT")) == 0;
@@ -64,6 +64,79 @@ static void placement_step(polar_hip_handle *h, int program_id, size_t frames, c
 		std::swap(h->scratch, h->scratch_spare);
 		t.done = true;
 	}
+}
+
+// Relay launches need kernels on `stream` and on the handle's second stream to run side by side. Streams share
+// the process's few hardware queues (four here) by an assignment nobody can ask for, and two streams on one queue
+// run their kernels one after the other - half a grid at a time, for the relay: much slower than one launch. So
+// the pair is tried once per caller's stream: one wavefront spins for a fraction of a millisecond, then one on each
+// stream; when the two took twice as long the second stream is replaced by a newly created one (consecutive streams go to different queues), four
+// tries; if none runs beside `stream`, relay launches stay off for it. Synchronises `stream` (once).
+__global__ void relay_probe_kernel(unsigned long long ticks)
+{
+	const unsigned long long t0 = __builtin_amdgcn_s_memtime(); // constant-rate counter: the loop ends whatever the clocks do
+	while (__builtin_amdgcn_s_memtime() - t0 < ticks)
+		__builtin_amdgcn_s_sleep(8);
+}
+
+static int relay_ready(polar_hip_handle *h, hipStream_t stream, bool *usable)
+{
+	if (h->relay_partner_known && h->relay_partner == stream) {
+		*usable = h->relay_usable;
+		return POLAR_OK;
+	}
+	if (!h->relay_fork) {
+		HIP_TRY(hipEventCreateWithFlags(&h->relay_fork, hipEventDisableTiming));
+		HIP_TRY(hipEventCreateWithFlags(&h->relay_join, hipEventDisableTiming));
+	}
+	const unsigned long long spin = 500000; // 0.2 - 0.5 ms of the shader clock's counter
+	auto probe = [&](bool both, float *ms) -> int {
+		HIP_TRY(hipEventRecord(h->ev0, stream));
+		HIP_TRY(hipEventRecord(h->relay_fork, stream));
+		HIP_TRY(hipStreamWaitEvent(h->relay, h->relay_fork, 0));
+		hipLaunchKernelGGL(relay_probe_kernel, dim3(1), dim3(64), 0, stream, spin);
+		if (both)
+			hipLaunchKernelGGL(relay_probe_kernel, dim3(1), dim3(64), 0, h->relay, spin);
+		HIP_TRY(hipGetLastError());
+		HIP_TRY(hipEventRecord(h->relay_join, h->relay));
+		HIP_TRY(hipStreamWaitEvent(stream, h->relay_join, 0));
+		HIP_TRY(hipEventRecord(h->ev1, stream));
+		HIP_TRY(hipEventSynchronize(h->ev1));
+		HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+		return POLAR_OK;
+	};
+	h->relay_usable = false;
+	std::vector<hipStream_t> rejected; // kept until the search is over: a stream created while they live goes to another queue
+	struct Drop {
+		std::vector<hipStream_t> &v;
+		~Drop()
+		{
+			for (hipStream_t s : v) {
+				(void)hipStreamSynchronize(s);
+				(void)hipStreamDestroy(s);
+			}
+		}
+	} drop{rejected};
+	for (int attempt = 0; attempt < 4 && !h->relay_usable; ++attempt) {
+		if (!h->relay || attempt) {
+			if (h->relay)
+				rejected.push_back(h->relay);
+			h->relay = nullptr;
+			HIP_TRY(hipStreamCreateWithFlags(&h->relay, hipStreamNonBlocking));
+		}
+		float one = 0, two = 0, warm = 0;
+		int rc;
+		if ((rc = probe(true, &warm)) || (rc = probe(false, &one)) || (rc = probe(true, &two))) // the first one loads the kernel
+			return rc;
+		h->relay_usable = two < 1.5f * one;
+		if (getenv("POLAR_HIP_DEBUG"))
+			fprintf(stderr, "polar_hip: relay stream %d: one spinning wavefront %.3f ms, one on each stream %.3f ms: %s\n", attempt, one, two, h->relay_usable ? "side by side" : "one after the other");
+	}
+	h->timed = false;
+	h->relay_partner = stream;
+	h->relay_partner_known = true;
+	*usable = h->relay_usable;
+	return POLAR_OK;
 }
 
 // Enqueues the decode of `frames` frames on `stream`. The kernel wants whole groups of 4Q frames
@@ -139,37 +212,43 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 		blocks = blocks + 8 - blocks % 8 <= max_blocks ? blocks + 8 - blocks % 8 : blocks - blocks % 8;
 	// Relay launches. The SIMD favours the older of its two wavefronts: in one launch of s sweeps the wavefronts
 	// of the first half of the grid finish 11 % before the others and their places stay empty for the rest of
-	// the kernel (profiles/r3_wave_lifetimes.txt). So a batch of several sweeps goes out as RELAY_PARTS launches
-	// of whole sweeps, alternately on the caller's stream and on a second one that is forked from it and joined
-	// to it again: the workgroups of launch p + 1 move into the places that those of launch p leave, and only
-	// the last launch has a tail. Two launches can be resident at once, so there are two sets of arenas, used
-	// alternately (launch p + 2 follows launch p on the same stream). Where the two streams share a hardware
-	// queue the launches run one after the other: the time of the single launch. Not with a configured share
-	// of the device (max_waves: the lanes of a caller who overlaps launches himself), not for ragged batches,
-	// and only while the second set of arenas fits. POLAR_HIP_RELAY=<parts> (0 or 1: off) overrides.
-	size_t parts = 1, part_sweeps = sweeps;
+	// the kernel (profiles/r3_wave_lifetimes.txt). So a batch of two sweeps and more goes out as two cohorts of
+	// half a grid each - one wavefront per SIMD - on two streams, the caller's and a second one that is forked
+	// from it and joined to it again, each with its own half of the arenas. Per segment of about four sweeps one
+	// cohort is sent as two launches and the other as one: the cohort that was launched first is the older and
+	// faster one on every SIMD until its first launch is through; its second launch is then the younger one,
+	// and the other cohort runs the second half of its work at the faster pace. Both finish together (496 instead
+	// of 512 in units of 1/120 of a walk; measured 212 instead of 219 ms at the headline). From segment to
+	// segment the cohorts change roles. Where the two streams share a hardware queue the launches run one after
+	// the other on half the device each, which is slower than one launch: the pair of streams is tried first (relay_ready). Not with a configured share of
+	// the device (max_waves: the lanes of a caller who overlaps launches himself), not for ragged batches.
+	size_t segments = 0; // 0: one launch
+	const size_t half = blocks / 2 / 8 * 8; // workgroups per cohort
 #if !defined(POLAR_PROFILE) && !defined(POLAR_SPAN)
 	{
-		const int relay_env = getenv("POLAR_HIP_RELAY") ? atoi(getenv("POLAR_HIP_RELAY")) : -1;
-		size_t want = relay_env >= 0 ? (size_t)relay_env : (size_t)RELAY_PARTS;
-		if (want > 1 && direct && sweeps >= 2 && !h->cfg_max_waves && blocks >= (size_t)per_cu * h->cus / 2 &&
-			(!block_dwords || budget.fits(2 * blocks * team * block_dwords * sizeof(u32)))) {
-			part_sweeps = (sweeps + want - 1) / want;
-			parts = (sweeps + part_sweeps - 1) / part_sweeps;
+		const char *relay_env = getenv("POLAR_HIP_RELAY");
+		// by default only for long launches (2^34 LLRs and more: -2 to -3 % at N = 2^16 with 2^20 frames; nothing to
+		// gain at N = 2^10 with 2^22 frames, whose walks take half a millisecond); POLAR_HIP_RELAY=2 forces it
+		const bool wanted = relay_env ? atoi(relay_env) > 1 : n * frames >= ((size_t)1 << 34);
+		if (wanted && direct && sweeps >= 2 && !h->cfg_max_waves && half && blocks >= (size_t)per_cu * h->cus / 2) {
+			bool usable = false;
+			if ((rc = relay_ready(h, stream, &usable)))
+				return rc;
+			if (usable)
+				segments = (sweeps + 3) / 4;
 		}
 	}
 #endif
-	const size_t sets = parts > 1 ? 2 : 1;
 	if (getenv("POLAR_HIP_DEBUG"))
 		fprintf(stderr, "polar_hip: scratch %p (%zu MiB) hot %p (%zu MiB)\n", h->scratch.p, h->scratch.bytes >> 20, h->hot.p, h->hot.bytes >> 20);
 	if (getenv("POLAR_HIP_DEBUG"))
 		fprintf(stderr, "polar_hip: decode Q=%d RL=%d team=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d hot levels <= %d\n", v->q, v->rl, v->team, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct, hot_top_for(v, lp.host.top, blocks * team));
-	if (getenv("POLAR_HIP_DEBUG") && parts > 1)
-		fprintf(stderr, "polar_hip: %zu relay launches of %zu sweeps\n", parts, part_sweeps);
+	if (getenv("POLAR_HIP_DEBUG") && segments)
+		fprintf(stderr, "polar_hip: relay launches: %zu segment(s) of three launches, %zu workgroups per cohort\n", segments, half);
 	h->last_shape[0] = 4 * v->q;
 	h->last_shape[1] = v->rl;
 	h->last_shape[2] = v->team;
-	h->last_launches = (int)parts;
+	h->last_launches = segments ? (int)(3 * segments) : 1;
 	DecodeArgs a = {};
 	a.prog = lp.dev[shape];
 	a.cw = cw;
@@ -206,22 +285,22 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 				h->hot.release();
 		}
 		if (tune_placement && timed && direct && stream == h->stream)
-			placement_step(h, program_id, frames, v, sets * blocks * team * block_dwords * sizeof(u32) + slack);
+			placement_step(h, program_id, frames, v, blocks * team * block_dwords * sizeof(u32) + slack);
 		else
 			h->placement.pending = false;
 		// experiments: POLAR_HIP_ARENA_PIECES = "<MiB per piece>[s]": the arenas as separately allocated pieces of
 		// device memory mapped into one range, in a shuffled order with an 's', the range aligned to the piece size with an 'a'
 		if (const char *pe = getenv("POLAR_HIP_ARENA_PIECES")) {
-			if (atoi(pe) > 0 && !strchr(pe, 'd') && (rc = h->scratch.reserve_chunked(sets * blocks * team * block_dwords * sizeof(u32) + slack, (size_t)atoi(pe) << 20, strchr(pe, 's') != nullptr, h->device, strchr(pe, 'a') != nullptr)))
+			if (atoi(pe) > 0 && !strchr(pe, 'd') && (rc = h->scratch.reserve_chunked(blocks * team * block_dwords * sizeof(u32) + slack, (size_t)atoi(pe) << 20, strchr(pe, 's') != nullptr, h->device, strchr(pe, 'a') != nullptr)))
 				return rc;
 		}
-		if ((rc = h->scratch.reserve_arenas(sets * blocks * team * block_dwords * sizeof(u32) + slack, h->device)))
+		if ((rc = h->scratch.reserve_arenas(blocks * team * block_dwords * sizeof(u32) + slack, h->device)))
 			return rc;
 		a.scratch = (u32 *)((char *)h->scratch.p + skew);
 		a.hot_top = hot_top_for(v, lp.host.top, blocks * team);
 		if (a.hot_top > v->rl) { // the wavefronts' hot levels side by side in one compact region
 			a.hot_dwords = ((size_t)v->q << (a.hot_top + 1)) - ((size_t)v->q << (v->rl + 1));
-			if ((rc = h->hot.reserve(sets * blocks * team * a.hot_dwords * sizeof(u32) + slack)))
+			if ((rc = h->hot.reserve(blocks * team * a.hot_dwords * sizeof(u32) + slack)))
 				return rc;
 			a.hot = (u32 *)((char *)h->hot.p + hskew);
 		}
@@ -236,32 +315,34 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 #endif
 	if (timed)
 		HIP_TRY(hipEventRecord(h->ev0, stream));
-	if (parts > 1) {
-		if (!h->relay) {
-			HIP_TRY(hipStreamCreateWithFlags(&h->relay, hipStreamNonBlocking));
-			HIP_TRY(hipEventCreateWithFlags(&h->relay_fork, hipEventDisableTiming));
-			HIP_TRY(hipEventCreateWithFlags(&h->relay_join, hipEventDisableTiming));
-		}
+	if (segments) {
 		HIP_TRY(hipEventRecord(h->relay_fork, stream));
 		HIP_TRY(hipStreamWaitEvent(h->relay, h->relay_fork, 0));
-		const size_t part_units = part_sweeps * blocks;
-		for (size_t p = 0; p < parts; ++p) {
-			const size_t first = p * part_units;
-			if (first >= units)
-				break;
-			const size_t count = p + 1 == parts || units - first < part_units ? units - first : part_units; // the last one takes what is left
+		// `count` units from unit `first` on as one launch of half a grid: the cohort on the second stream uses the arenas from `half` on
+		auto go = [&](size_t first, size_t count, bool on_relay) -> int {
+			if (!count)
+				return POLAR_OK;
 			DecodeArgs ap = a;
 			ap.cw = a.cw + first * fpw;
 			ap.msg = a.msg + first * fpw;
 			ap.groups = (u32)(count * team);
-			if (p & 1) { // the second set of arenas
+			if (on_relay) {
 				if (ap.scratch)
-					ap.scratch += blocks * team * block_dwords;
+					ap.scratch += half * team * block_dwords;
 				if (ap.hot)
-					ap.hot += blocks * team * a.hot_dwords;
+					ap.hot += half * team * a.hot_dwords;
 			}
-			hipLaunchKernelGGL(v->fn, dim3((unsigned)blocks), dim3(64 * (unsigned)team), 0, (p & 1) ? h->relay : stream, ap);
+			hipLaunchKernelGGL(v->fn, dim3((unsigned)half), dim3(64 * (unsigned)team), 0, on_relay ? h->relay : stream, ap);
 			HIP_TRY(hipGetLastError());
+			return POLAR_OK;
+		};
+		const size_t seg_units = (units + segments - 1) / segments;
+		for (size_t seg = 0; seg < segments && seg * seg_units < units; ++seg) {
+			const size_t u0 = seg * seg_units, n = (u0 + seg_units < units ? u0 + seg_units : units) - u0;
+			const size_t once = n / 2, first_half = (n - once) / 2, second_half = n - once - first_half;
+			const bool twice_on_relay = seg & 1; // the cohort that goes out as two launches: launched first, so the older one to begin with
+			if ((rc = go(u0, first_half, twice_on_relay)) || (rc = go(u0 + first_half + second_half, once, !twice_on_relay)) || (rc = go(u0 + first_half, second_half, twice_on_relay)))
+				return rc;
 		}
 		HIP_TRY(hipEventRecord(h->relay_join, h->relay));
 		HIP_TRY(hipStreamWaitEvent(stream, h->relay_join, 0));

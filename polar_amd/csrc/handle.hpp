@@ -152,6 +152,8 @@ struct polar_hip_handle {
 	// relay launches (decode_launch.hpp): the second stream and the events that fork it from and join it to the caller's
 	hipStream_t relay = nullptr;
 	hipEvent_t relay_fork = nullptr, relay_join = nullptr;
+	hipStream_t relay_partner = nullptr; // the stream `relay` was last checked against (relay_ready): kernels on the two run side by side ...
+	bool relay_partner_known = false, relay_usable = false; // ... or, if no second stream was found that does, relay launches are off for it
 	// host-buffer pipeline (polar_hip_decode with pinned POLAR_HOST buffers): copy-in and copy-out
 	// streams beside `stream`, and per staging slot the events "copied in", "decoded", "copied out"
 	hipStream_t pipe_in = nullptr, pipe_out = nullptr;

@@ -850,11 +850,10 @@ def test_arena_placement_choice_keeps_results(oracle, golden, capfd, monkeypatch
 @pytest.mark.gpu
 @pytest.mark.parametrize("M,frames", [(10, 512 * 2001), (12, 512 * 601)])
 def test_relay_launches_keep_results(oracle, monkeypatch, M, frames):
-    """decode_launch.hpp, relay launches: a batch of several sweeps goes out as up to four launches of whole
-    sweeps, alternately on the call's stream and on a second one, with two sets of arenas. The decisions must be
-    those of the single launch (POLAR_HIP_RELAY=1) bit for bit, for a batch whose last launch is a partial one,
-    on repeated calls (the second set of arenas keeps the last call's contents), and the oracle's on a sample
-    of frames from every launch."""
+    """decode_launch.hpp, relay launches: a batch of several sweeps goes out as two cohorts of half a grid each on
+    two streams, three launches per segment of about four sweeps. The decisions must be those of the single
+    launch (POLAR_HIP_RELAY=1) bit for bit, for a batch that does not divide evenly, on repeated calls (the
+    arenas keep the last call's contents), and the oracle's on a sample of frames from every launch."""
     import polar_amd
 
     N = 1 << M
@@ -873,12 +872,11 @@ def test_relay_launches_keep_results(oracle, monkeypatch, M, frames):
         for _ in range(2):
             out = torch.full((N // 2, frames), 77, dtype=torch.int8, device="cuda")
             dec(out, llr, prog)
-            assert 1 < sess.last_decode_launches() <= int(parts), (parts, sess.last_decode_launches(), sess.last_decode_shape())
+            assert sess.last_decode_launches() > 1 and sess.last_decode_launches() % 3 == 0, (parts, sess.last_decode_launches(), sess.last_decode_shape())
             assert bool((out == one).all())
-    monkeypatch.delenv("POLAR_HIP_RELAY")
-    out = torch.full((N // 2, frames), 77, dtype=torch.int8, device="cuda")
-    dec(out, llr, prog)
-    assert sess.last_decode_launches() > 1 and bool((out == one).all())
+    monkeypatch.delenv("POLAR_HIP_RELAY")  # the default: relay launches only from 2^34 LLRs on
+    dec(torch.empty_like(out), llr, prog)
+    assert sess.last_decode_launches() == 1
     cols = np.unique(np.concatenate([np.arange(0, 64), np.linspace(0, frames - 1, 200).astype(np.int64), np.arange(frames - 64, frames)]))
     sample = llr[:, torch.from_numpy(cols).cuda()].cpu().numpy()
     want = oracle.decode(sample, prog)

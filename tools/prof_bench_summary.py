@@ -35,7 +35,7 @@ if launches > 1:
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
         rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f)) if "sc_decode" in r["Kernel_Name"]))
         longest = max(e - b for b, e in rows)
-        rows = [r for r in rows if r[1] - r[0] >= 0.25 * longest]
+        rows = [r for r in rows if r[1] - r[0] >= 0.1 * longest]
         spans = [max(e for _, e in rows[i:i + launches]) - rows[i][0] for i in range(0, len(rows) - launches + 1, launches)]
         sums = [sum(e - b for b, e in rows[i:i + launches]) for i in range(0, len(rows) - launches + 1, launches)]
         if spans:
@@ -47,9 +47,11 @@ for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), r
             vals[row["Counter_Name"]].append(float(row["Counter_Value"]))
 res = {}
 for k, v in sorted(vals.items()):
-    big = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v
-    res[k] = sum(big) / len(big) * launches  # counters are per dispatch (serialised under --pmc): one decode = `launches` of them
-    print("%-22s %d decode dispatches, %d batch-sized, mean %.6g per decode (%d dispatches each)" % (k, len(v), len(big), res[k], launches))
+    # counters are per dispatch (serialised under --pmc); one decode of the batch = `launches` dispatches of unequal sizes
+    # (relay launches), so: the sum over the dispatches of batch-sized decodes / the number of such decodes
+    big = [x for x in v if x >= (0.5 if launches == 1 else 0.1) * max(v)] if max(v) > 0 else v
+    res[k] = sum(big) / (len(big) / launches)
+    print("%-22s %d decode dispatches, %d of batch-sized decodes, %.6g per decode (%d dispatches each)" % (k, len(v), len(big), res[k], launches))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # library_sha16(): the kernel sources these counters are taken on
 

@@ -60,9 +60,7 @@ while time.time() - t0 < a.seconds:
     one = torch.empty((K, frames), dtype=torch.int8, device="cuda")
     os.environ["POLAR_HIP_RELAY"] = "1"
     dec(one, flat, prog)
-    os.environ.pop("POLAR_HIP_RELAY")
-    if rng.random() < 0.3:
-        os.environ["POLAR_HIP_RELAY"] = str(int(rng.integers(2, 4)))
+    os.environ["POLAR_HIP_RELAY"] = "2"  # relay launches whatever the size of the batch
     wide_out = torch.full((K, mp), 91, dtype=torch.int8, device="cuda")
     out = wide_out[:, :frames]
     dec(out, llr, prog)
