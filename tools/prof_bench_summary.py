@@ -25,7 +25,7 @@ fpw, rl = opt("--fpw", 0), opt("--lds-level", 0)
 kernel_ns = None
 for row in csv.DictReader(open(os.path.join(out, "kernel_stats.csv"))):
     print("%-70s calls %6s avg_ns %14s pct %s" % (row["Name"][:70], row["Calls"], row["AverageNs"], row["Percentage"]))
-launches = 1
+launches, decodes = 1, 0
 try:
     launches = int(json.loads(open(os.path.join(out, "bench_under_trace.json")).readline())["roofline"].get("launches_per_decode", 1))
 except Exception:
@@ -36,6 +36,7 @@ if launches > 1:
         rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f)) if "sc_decode" in r["Kernel_Name"]))
         longest = max(e - b for b, e in rows)
         rows = [r for r in rows if r[1] - r[0] >= 0.1 * longest]
+        decodes = len(rows) // launches
         spans = [max(e for _, e in rows[i:i + launches]) - rows[i][0] for i in range(0, len(rows) - launches + 1, launches)]
         sums = [sum(e - b for b, e in rows[i:i + launches]) for i in range(0, len(rows) - launches + 1, launches)]
         if spans:
@@ -49,9 +50,11 @@ res = {}
 for k, v in sorted(vals.items()):
     # counters are per dispatch (serialised under --pmc); one decode of the batch = `launches` dispatches of unequal sizes
     # (relay launches), so: the sum over the dispatches of batch-sized decodes / the number of such decodes
+    # (relay launches); under --pmc the relay's probe finds the streams serialised and the decode stays one launch, so
+    # the number of decodes comes from the trace pass of the same command
     big = [x for x in v if x >= (0.5 if launches == 1 else 0.1) * max(v)] if max(v) > 0 else v
-    res[k] = sum(big) / (len(big) / launches)
-    print("%-22s %d decode dispatches, %d of batch-sized decodes, %.6g per decode (%d dispatches each)" % (k, len(v), len(big), res[k], launches))
+    res[k] = sum(big) / (decodes if launches > 1 and decodes else len(big))
+    print("%-22s %d decode dispatches, %d of batch-sized decodes, %.6g per decode of the batch" % (k, len(v), len(big), res[k]))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # library_sha16(): the kernel sources these counters are taken on
 
