@@ -63,7 +63,7 @@ E_LEVELS = range(10, 17)
 E_SNRS = (-2.0, -1.5, -1.0, -0.5)
 
 
-SETTLE_CALLS = 4  # untimed decode calls of the set-up in which the library settles the placement of its arenas
+SETTLE_CALLS = 6  # untimed decode calls of the set-up in which the library settles the placement of its arenas
 
 
 def parse(argv=None):

@@ -11,8 +11,9 @@
 // each, the best one is kept. Results do not depend on it. Arenas of 1 GiB and more, and only while a
 // second copy fits the free device memory; POLAR_HIP_PLACEMENT=0 turns it off.
 enum { PLACEMENT_CANDIDATES = 3 };
-static void placement_step(polar_hip_handle *h, int program_id, size_t frames, const KernelVariant *v, size_t bytes)
+static void placement_step(polar_hip_handle *h, int program_id, size_t frames, const KernelVariant *v, size_t bytes, bool relay_possible)
 {
+	typedef polar_hip_handle::Placement P;
 	static const bool off = getenv("POLAR_HIP_PLACEMENT") && atoi(getenv("POLAR_HIP_PLACEMENT")) == 0;
 	polar_hip_handle::Placement &t = h->placement;
 	const bool same = t.program == program_id && t.frames == frames && t.fn == (const void *)v->fn && t.bytes == bytes;
@@ -32,9 +33,31 @@ static void placement_step(polar_hip_handle *h, int program_id, size_t frames, c
 		}
 		return;
 	}
-	if (!t.pending || t.done)
+	if (t.done) { // the placement is chosen; what is left is the call that ran as relay launches, if there was one
+		float trial = 0;
+		if (t.relay == P::RELAY_TRIAL && t.pending) {
+			if (hipEventSynchronize(h->ev1) == hipSuccess && hipEventElapsedTime(&trial, h->ev0, h->ev1) == hipSuccess && trial > 0)
+				t.relay = trial < 0.99f * t.best_ms ? P::RELAY_ON : P::RELAY_OFF; // it has to gain a percent
+			else
+				t.relay = P::RELAY_OFF;
+			if (getenv("POLAR_HIP_DEBUG"))
+				fprintf(stderr, "polar_hip: relay launches %.2f ms against %.2f ms for one launch: %s\n", trial, t.best_ms, t.relay == P::RELAY_ON ? "kept" : "dropped");
+		}
+		t.pending = false;
+		return;
+	}
+	if (!t.pending)
 		return;
 	t.pending = false;
+	struct Finish { // whichever way the comparison of placements ends: the next call tries relay launches
+		P &t;
+		bool relay_possible;
+		~Finish()
+		{
+			if (t.done && relay_possible && t.relay == P::RELAY_UNTESTED)
+				t.relay = P::RELAY_TRIAL;
+		}
+	} finish{t, relay_possible};
 	float ms = 0;
 	bool ok = hipEventSynchronize(h->ev1) == hipSuccess && hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess && ms > 0;
 	ok = ok && hipStreamSynchronize(h->stream) == hipSuccess;
@@ -224,31 +247,21 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	// the device (max_waves: the lanes of a caller who overlaps launches himself), not for ragged batches.
 	size_t segments = 0; // 0: one launch
 	const size_t half = blocks / 2 / 8 * 8; // workgroups per cohort
+	bool relay_possible = false, relay_forced = false;
 #if !defined(POLAR_PROFILE) && !defined(POLAR_SPAN)
 	{
-		const char *relay_env = getenv("POLAR_HIP_RELAY");
-		// by default only for long launches (2^34 LLRs and more: -2 to -3 % at N = 2^16 with 2^20 frames; nothing to
-		// gain at N = 2^10 with 2^22 frames, whose walks take half a millisecond); POLAR_HIP_RELAY=2 forces it
-		const bool wanted = relay_env ? atoi(relay_env) > 1 : n * frames >= ((size_t)1 << 34);
-		if (wanted && direct && sweeps >= 2 && !h->cfg_max_waves && half && blocks >= (size_t)per_cu * h->cus / 2) {
-			bool usable = false;
-			if ((rc = relay_ready(h, stream, &usable)))
-				return rc;
-			if (usable)
-				segments = (sweeps + 3) / 4;
-		}
+		const char *relay_env = getenv("POLAR_HIP_RELAY"); // 0 / 1: never; 2: whenever possible; unset: where the clock says so (placement_step)
+		relay_possible = (!relay_env || atoi(relay_env) > 1) && direct && sweeps >= 2 && !h->cfg_max_waves && half && blocks >= (size_t)per_cu * h->cus / 2;
+		relay_forced = relay_possible && relay_env;
 	}
 #endif
 	if (getenv("POLAR_HIP_DEBUG"))
 		fprintf(stderr, "polar_hip: scratch %p (%zu MiB) hot %p (%zu MiB)\n", h->scratch.p, h->scratch.bytes >> 20, h->hot.p, h->hot.bytes >> 20);
 	if (getenv("POLAR_HIP_DEBUG"))
 		fprintf(stderr, "polar_hip: decode Q=%d RL=%d team=%d groups=%zu blocks=%zu (%d per CU x %d CUs) lds=%zu B direct=%d hot levels <= %d\n", v->q, v->rl, v->team, groups, blocks, per_cu, h->cus, v->lds_bytes, (int)direct, hot_top_for(v, lp.host.top, blocks * team));
-	if (getenv("POLAR_HIP_DEBUG") && segments)
-		fprintf(stderr, "polar_hip: relay launches: %zu segment(s) of three launches, %zu workgroups per cohort\n", segments, half);
 	h->last_shape[0] = 4 * v->q;
 	h->last_shape[1] = v->rl;
 	h->last_shape[2] = v->team;
-	h->last_launches = segments ? (int)(3 * segments) : 1;
 	DecodeArgs a = {};
 	a.prog = lp.dev[shape];
 	a.cw = cw;
@@ -285,7 +298,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 				h->hot.release();
 		}
 		if (tune_placement && timed && direct && stream == h->stream)
-			placement_step(h, program_id, frames, v, blocks * team * block_dwords * sizeof(u32) + slack);
+			placement_step(h, program_id, frames, v, blocks * team * block_dwords * sizeof(u32) + slack, relay_possible);
 		else
 			h->placement.pending = false;
 		// experiments: POLAR_HIP_ARENA_PIECES = "<MiB per piece>[s]": the arenas as separately allocated pieces of
@@ -304,6 +317,28 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 				return rc;
 			a.hot = (u32 *)((char *)h->hot.p + hskew);
 		}
+	}
+	// Relay launches pay for some workloads and cost for others (N = 2^16: -2.3 % with 2^20 frames, +2.5 % with 2^21,
+	// +12 % with 3 * 2^18; N = 2^12 ... 2^15: +1 to +6 %, profiles/r3_relay_sizes.txt), so they are not a default
+	// but a measurement: a handle that decodes the same resident batch again and again (the one whose arena
+	// placement is chosen by the clock) runs one call as relay launches once the placement stands, and keeps them
+	// if that call was a percent faster than the best single launch.
+	{
+		typedef polar_hip_handle::Placement P;
+		P &t = h->placement;
+		const bool watched = tune_placement && timed && direct && stream == h->stream && t.program == program_id && t.done;
+		if (relay_forced || (relay_possible && watched && (t.relay == P::RELAY_TRIAL || t.relay == P::RELAY_ON))) {
+			bool usable = false;
+			if ((rc = relay_ready(h, stream, &usable)))
+				return rc;
+			if (usable)
+				segments = (sweeps + 3) / 4;
+			else if (!relay_forced)
+				t.relay = P::RELAY_OFF;
+		}
+		if (getenv("POLAR_HIP_DEBUG") && segments)
+			fprintf(stderr, "polar_hip: relay launches: %zu segment(s) of three launches, %zu workgroups per cohort\n", segments, half);
+		h->last_launches = segments ? (int)(3 * segments) : 1;
 	}
 	a.prof = nullptr;
 #if defined(POLAR_PROFILE) || defined(POLAR_SPAN)
@@ -336,12 +371,16 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 			HIP_TRY(hipGetLastError());
 			return POLAR_OK;
 		};
+		// a segment's units in whole walks of half a grid: cohort Y takes s walks per wavefront in one launch, cohort X
+		// the rest as floor(s / 2) walks in its first launch and what is left in its second
 		const size_t seg_units = (units + segments - 1) / segments;
 		for (size_t seg = 0; seg < segments && seg * seg_units < units; ++seg) {
 			const size_t u0 = seg * seg_units, n = (u0 + seg_units < units ? u0 + seg_units : units) - u0;
-			const size_t once = n / 2, first_half = (n - once) / 2, second_half = n - once - first_half;
+			const size_t walks = (n + 2 * half - 1) / (2 * half);
+			const size_t once = n < walks * half ? n : walks * half, twice = n - once;
+			const size_t first_part = twice < walks / 2 * half ? twice : walks / 2 * half, second_part = twice - first_part;
 			const bool twice_on_relay = seg & 1; // the cohort that goes out as two launches: launched first, so the older one to begin with
-			if ((rc = go(u0, first_half, twice_on_relay)) || (rc = go(u0 + first_half + second_half, once, !twice_on_relay)) || (rc = go(u0 + first_half, second_half, twice_on_relay)))
+			if ((rc = go(u0, first_part, twice_on_relay)) || (rc = go(u0 + twice, once, !twice_on_relay)) || (rc = go(u0 + first_part, second_part, twice_on_relay)))
 				return rc;
 		}
 		HIP_TRY(hipEventRecord(h->relay_join, h->relay));
@@ -411,7 +450,7 @@ static int launch_decode(polar_hip_handle *h, int program_id, int8_t *message, c
 	if (timed) {
 		HIP_TRY(hipEventRecord(h->ev1, stream));
 		h->timed = true;
-		if (tune_placement && direct && stream == h->stream && h->placement.program == program_id && !h->placement.done)
+		if (tune_placement && direct && stream == h->stream && h->placement.program == program_id && (!h->placement.done || (h->placement.relay == polar_hip_handle::Placement::RELAY_TRIAL && segments)))
 			h->placement.pending = true;
 	}
 	if (!direct && rows)

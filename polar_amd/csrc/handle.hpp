@@ -186,6 +186,10 @@ struct polar_hip_handle {
 		const void *fn = nullptr;
 		float best_ms = 0;
 		bool pending = false, done = false;
+		// relay launches for this workload (decode_launch.hpp): decided by the clock once the placement is chosen:
+		// one call as relay launches against the best single launch
+		enum { RELAY_UNTESTED, RELAY_TRIAL, RELAY_ON, RELAY_OFF };
+		int relay = RELAY_UNTESTED;
 	} placement;
 	DeviceBuffer set_table; // polar_hip_decode_set: the argument table of the common launch
 	int last_shape[3] = {0, 0, 0}; // frames per wavefront, LDS level, team of the last decode launch
