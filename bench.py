@@ -63,7 +63,7 @@ E_LEVELS = range(10, 17)
 E_SNRS = (-2.0, -1.5, -1.0, -0.5)
 
 
-SETTLE_CALLS = 6  # untimed decode calls of the set-up in which the library settles the placement of its arenas
+SETTLE_CALLS = 6  # untimed decode calls of the set-up in which the library settles the placement of its arenas and whether to use relay launches
 
 
 def parse(argv=None):
@@ -440,7 +440,8 @@ def main():
         sess.random_message(msg_true, seed, first)
     # Part of the set-up, before the warm-up steps: the library looks at a few placements of its scratch
     # arenas, one call each, and keeps the fastest (decode_launch.hpp, placement_step: where the driver puts
-    # 20 GiB of arenas decides up to 5 % of the kernel time). SETTLE_CALLS calls see that through.
+    # 20 GiB of arenas decides up to 5 % of the kernel time), then runs one call as relay launches and keeps
+    # them if they are faster. SETTLE_CALLS calls see both through.
     for _ in range(SETTLE_CALLS):
         dec(out, llr, prog)
     for _ in range(args.warmup):

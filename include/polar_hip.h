@@ -287,15 +287,17 @@ int polar_hip_decode_pitched(polar_hip_handle *h, int program_id, int8_t *messag
                              const int8_t *codeword, size_t codeword_pitch, size_t frames);
 size_t polar_hip_row_pitch(size_t frames);
 
-/* Kernel launches of the last decode on this handle: 1, or the number of relay launches a long batch went out
- * as (2^34 LLRs and more, two sweeps and more): two cohorts of half a grid each - one wavefront per SIMD - on
- * the call's stream and on a second stream of the handle that is forked from it and joined to it again, each
- * with its half of the arenas; per segment of about four sweeps one cohort is sent as two launches, the other as
- * one, so that the cohort the SIMDs favour (the older one: it runs 11 % faster) changes in the middle and both
- * finish together: 212 instead of 219 ms at N = 2^16 with 2^20 frames, no more memory. The pair of streams is
- * tried once (two short kernels must run side by side, else another second stream is taken, else one launch).
- * Same results either way; POLAR_HIP_RELAY=1 in the environment turns it off, =2 forces it for short batches.
- * No counterpart in the reference (testbench.cc:170-175 is one loop). */
+/* Kernel launches of the last decode on this handle: 1, or the number of relay launches the batch went out
+ * as: two cohorts of half a grid each - one wavefront per SIMD - on the call's stream and on a second stream of
+ * the handle that is forked from it and joined to it again, each with its half of the arenas; per segment of
+ * about four sweeps one cohort is sent as two launches, the other as one, so that the cohort the SIMDs favour
+ * (the older one: it runs 11 % faster) changes in the middle and both finish together (212 instead of 219 ms at
+ * N = 2^16 with 2^20 frames, no more memory). Not a default but a measurement: a handle that decodes the same
+ * resident batch again and again with polar_hip_decode (the one whose arena placement is chosen by the clock)
+ * runs one call that way once the placement stands and keeps it if that call was a percent faster than the
+ * best single launch; the pair of streams is tried first (two short kernels must run side by side). Same
+ * results either way; POLAR_HIP_RELAY=1 in the environment turns it off, =2 forces it wherever a batch has two
+ * sweeps and more. No counterpart in the reference (testbench.cc:170-175 is one loop). */
 int polar_hip_last_decode_launches(polar_hip_handle *h);
 
 /* Milliseconds the GPU spent in the decode kernel of the last polar_hip_decode call (first launch's start to
