@@ -25,22 +25,25 @@ fpw, rl = opt("--fpw", 0), opt("--lds-level", 0)
 kernel_ns = None
 for row in csv.DictReader(open(os.path.join(out, "kernel_stats.csv"))):
     print("%-70s calls %6s avg_ns %14s pct %s" % (row["Name"][:70], row["Calls"], row["AverageNs"], row["Percentage"]))
-launches, decodes = 1, 0
+launches, decodes, steps = 1, 0, 0
 try:
-    launches = int(json.loads(open(os.path.join(out, "bench_under_trace.json")).readline())["roofline"].get("launches_per_decode", 1))
+    line = json.loads(open(os.path.join(out, "bench_under_trace.json")).readline())
+    launches = int(line["roofline"].get("launches_per_decode", 1))
+    steps = int(line["steps"])
+    decodes = int(line["config"].get("setup_decode_calls", 0)) + int(line["warmup"]) + steps  # decodes of the batch in one run of the command
 except Exception:
     pass
 if launches > 1:
-    # relay launches: one decode = `launches` overlapping dispatches; its time is the first start to the last end
+    # relay launches: one decode = `launches` overlapping dispatches; its time is the first start to the last end.
+    # The timed steps are the last ones of the run (the set-up calls before them are single launches until the
+    # handle has decided for the relay).
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
         rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(f)) if "sc_decode" in r["Kernel_Name"]))
-        longest = max(e - b for b, e in rows)
-        rows = [r for r in rows if r[1] - r[0] >= 0.1 * longest]
-        decodes = len(rows) // launches
+        rows = rows[-steps * launches:]
         spans = [max(e for _, e in rows[i:i + launches]) - rows[i][0] for i in range(0, len(rows) - launches + 1, launches)]
         sums = [sum(e - b for b, e in rows[i:i + launches]) for i in range(0, len(rows) - launches + 1, launches)]
         if spans:
-            print("decodes of %d relay launches each: %d; first start to last end, mean %.0f ns (the launches overlap: their durations add up to %.0f ns)" % (launches, len(spans), sum(spans) / len(spans), sum(sums) / len(sums)))
+            print("the %d timed decodes, %d relay launches each: first start to last end, mean %.0f ns (the launches overlap: their durations add up to %.0f ns)" % (len(spans), launches, sum(spans) / len(spans), sum(sums) / len(sums)))
 vals = defaultdict(list)
 for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
@@ -53,7 +56,7 @@ for k, v in sorted(vals.items()):
     # (relay launches); under --pmc the relay's probe finds the streams serialised and the decode stays one launch, so
     # the number of decodes comes from the trace pass of the same command
     big = [x for x in v if x >= (0.5 if launches == 1 else 0.1) * max(v)] if max(v) > 0 else v
-    res[k] = sum(big) / (decodes if launches > 1 and decodes else len(big))
+    res[k] = sum(big) / (decodes if launches > 1 and decodes else len(big))  # under --pmc every decode is one launch: len(big) == decodes there
     print("%-22s %d decode dispatches, %d of batch-sized decodes, %.6g per decode of the batch" % (k, len(v), len(big), res[k]))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # library_sha16(): the kernel sources these counters are taken on
